@@ -1,0 +1,129 @@
+/* nhans_hip.h -- C ABI of libnhans_hip.so, the MI355X (gfx950) implementation of the N-HANS
+ * per-frame inference hot path.
+ *
+ * The reference has no FFI/plugin interface: its hot path is a chain of TensorFlow graph calls
+ * inside apply_snc / apply_separator.  Each entry point below replaces one link of that chain
+ * (citations relative to /root/reference; SN = N_HANS___Selective_Noise, SS = N_HANS___Source_Separation):
+ *
+ *   nhans_stft_features  <- tf.signal.stft + log(abs+1e-5) + angle       SN/apply.py:368-375  (SS/apply.py:316-322)
+ *   nhans_embed          <- model(): 'embedding' scopes                   SN/main.py:190-216   (SS/main.py:206-229)
+ *   nhans_mask_net       <- strided_crop + minibatch loop + model() stack SN/apply.py:378,398-450, SN/main.py:219-242
+ *                           (tensor contract: feed mixedph/noise*contextph, fetch add_72:0, SN/apply.py:434-446)
+ *   nhans_istft          <- recover_samples_from_spectrum                 SN/apply.py:189-204  (SS/apply.py:158-171)
+ *   nhans_enhance_clips  <- apply_snc / apply_separator after handle_signals  SN/apply.py:368-458 (SS/apply.py:316-393)
+ *
+ * Conventions: plain C, no exceptions cross the boundary.  Every int-returning function gives 0
+ * on success or a negative NHANS_E* code, with a message in nhans_last_error() (thread-local).
+ * `*_dev` pointers are device (HBM) addresses owned by the caller; `*_host` pointers are host
+ * arrays.  `stream` is a hipStream_t (0 = default stream); all work is enqueued on it and the
+ * functions do not synchronise.  The library owns only its context: folded weights and a
+ * workspace that grows on demand.  One context per (device, model); a context is not
+ * thread-safe, distinct contexts are independent.
+ *
+ * Ragged batches: clip c owns samples [sample_offsets[c], sample_offsets[c+1]) of the wav
+ * buffer and frames [frame_offsets[c], frame_offsets[c+1]) of every [T_total, 201] tensor, with
+ * T_c = nhans_num_frames(n_c) = 1 + (n_c - 400) / 160 for n_c >= 400 (the caller has already
+ * applied the reference's normalise + tail-trim, SN/apply.py:150-161).
+ */
+#ifndef NHANS_HIP_H
+#define NHANS_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NHANS_ABI_VERSION 1
+
+#define NHANS_DENOISER 0   /* SN model: emb_a = positive context (--pos), emb_b = negative (--neg) */
+#define NHANS_SEPARATOR 1  /* SS model: emb_a = interferer  (--neg),      emb_b = target   (--pos) */
+
+#define NHANS_OK 0
+#define NHANS_EINVAL (-1)   /* bad argument / malformed blob */
+#define NHANS_EHIP (-2)     /* HIP runtime error */
+#define NHANS_ENOMEM (-3)   /* workspace allocation failed */
+#define NHANS_ESHORT (-4)   /* a conditioning recording yields fewer than 200 frames */
+
+#define NHANS_WIN 400
+#define NHANS_HOP 160
+#define NHANS_BINS 201
+#define NHANS_MIX_WIN 35
+#define NHANS_CTX_FRAMES 200
+#define NHANS_EMB 512
+
+typedef struct nhans_ctx nhans_ctx;
+
+int nhans_abi_version(void);
+const char* nhans_last_error(void);
+
+/* frames of an n-sample (already trimmed or not) signal: 0 if n < 400, else 1 + (n-400)/160 */
+int64_t nhans_num_frames(int64_t nsamples);
+
+/* Build a context from the folded-weights blob produced by nhans_amd.fold.fold_weights()
+ * (format documented in n-hans_amd/fold.py).  The blob is copied to the device. */
+int nhans_create(int model_kind, const void* folded_blob, size_t nbytes, int device_id, nhans_ctx** out);
+void nhans_destroy(nhans_ctx* ctx);
+
+/* Options: "frames_per_chunk" (mask-net frame windows per pass, default 1024),
+ *          "contexts_per_chunk" (embedding-tower images per pass, default 64),
+ *          "profile" (1: time every kernel launch with hipEvents on the launch stream). */
+int nhans_set_option(nhans_ctx* ctx, const char* key, int64_t value);
+
+/* Bytes of device workspace the context would hold for a batch of this shape. */
+size_t nhans_workspace_bytes(nhans_ctx* ctx, int64_t total_frames, int nclips);
+
+/* wav -> log-magnitude and phase.  max_frames_per_clip > 0 truncates every clip to its first
+ * frames (used for the 200-frame conditioning contexts, SN/apply.py:381).  Outputs are
+ * [sum_c min(T_c, max), 201] float32; phase_dev may be NULL. */
+int nhans_stft_features(nhans_ctx* ctx, const float* wav_dev, const int64_t* sample_offsets_host,
+                        int nclips, int max_frames_per_clip, float* logmag_dev, float* phase_dev,
+                        void* stream);
+
+/* Embedding tower: n context images [n,200,201] -> [n,512]. */
+int nhans_embed(nhans_ctx* ctx, const float* ctx_logmag_dev, int n, float* emb_out_dev, void* stream);
+
+/* Conditioned residual stack + head over every frame of every clip.  logmag [T_total,201];
+ * emb_a/emb_b [nclips,512] in resnet_block argument order (see NHANS_DENOISER/SEPARATOR).
+ * logits_out_dev (nullable) receives `out` = last_dense output; denoised_out_dev receives
+ * logmag + out (the reference's add_72:0).  Sliding 35-frame windows are gathered on the fly
+ * with rows outside the clip equal to 0.0 (SN/apply.py:170-186). */
+int nhans_mask_net(nhans_ctx* ctx, const float* logmag_dev, const int64_t* frame_offsets_host,
+                   int nclips, const float* emb_a_dev, const float* emb_b_dev,
+                   float* logits_out_dev, float* denoised_out_dev, void* stream);
+
+/* exp/polar -> 400-point inverse real FFT -> synthesis window -> overlap-add.  Clip c writes
+ * (T_c-1)*160+400 samples at wav_out_dev + out_offsets_host[c]. */
+int nhans_istft(nhans_ctx* ctx, const float* logmag_dev, const float* phase_dev,
+                const int64_t* frame_offsets_host, int nclips, const int64_t* out_offsets_host,
+                float* wav_out_dev, void* stream);
+
+/* Whole hot path for a ragged batch.  Mixture clips must be trimmed so (n-400)%160 == 0;
+ * context clips need >= 32,240 samples (only their first 200 frames are used).  ctx_a/ctx_b
+ * follow the emb_a/emb_b convention.  denoised_wav_dev and mixed_wav_dev (nullable: the
+ * reference's *mixed_processed.wav round trip) use the mixture's sample offsets.  Optional
+ * taps (nullable): logmag_out_dev/phase_out_dev/logits_out_dev [T_total,201], emb_out_dev
+ * [2*nclips,512] (a-rows then b-rows). */
+int nhans_enhance_clips(nhans_ctx* ctx, const float* mix_wav_dev, const int64_t* mix_offsets_host,
+                        int nclips, const float* ctx_a_wav_dev, const int64_t* ctx_a_offsets_host,
+                        const float* ctx_b_wav_dev, const int64_t* ctx_b_offsets_host,
+                        float* denoised_wav_dev, float* mixed_wav_dev, float* logmag_out_dev,
+                        float* phase_out_dev, float* logits_out_dev, float* emb_out_dev, void* stream);
+
+/* Debug tap: run the stack on `nframes` frame windows starting at global frame `frame0` and copy
+ * the NHWC output of main block `block` (0..7; 8 = last_conv) to out_dev. */
+int nhans_debug_block_output(nhans_ctx* ctx, const float* logmag_dev, const int64_t* frame_offsets_host,
+                             int nclips, const float* emb_a_dev, const float* emb_b_dev,
+                             int64_t frame0, int nframes, int block, float* out_dev, void* stream);
+
+/* Profiling (option "profile" = 1): per-kernel launch counts, summed milliseconds and summed
+ * algorithmic FLOPs / bytes since the last reset, as a JSON object written to buf.  Synchronises
+ * the recorded events.  Returns the number of bytes needed (excluding the NUL). */
+int nhans_profile_json(nhans_ctx* ctx, char* buf, size_t buflen);
+int nhans_profile_reset(nhans_ctx* ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NHANS_HIP_H */

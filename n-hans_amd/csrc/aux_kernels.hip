@@ -1,0 +1,158 @@
+// Bandwidth-bound helper kernels of the N-HANS hot path: the 1-channel first-layer convolution,
+// sliding-window gather, global average pool, conditioning projections, frame index.
+#include "nhans_kernels.h"
+
+namespace nhans {
+
+// ---------------------------------------------------------------------------------------------
+// First conv of a block whose input is the 1-channel log-magnitude image (K = KH*KW <= 32):
+// main stack resblock1_1_conv1 (4x4, SN/main.py:162-168) and the tower's noise_resblock1_1_conv1
+// (8x4 stride (3,2), SN/main.py:104-107).  16 lanes x float4 cover the 64 output channels of one
+// pixel, so every store is a full 256-byte NHWC pixel; the taps live in LDS.
+__global__ void __launch_bounds__(256) direct_conv64(const DirectArgs a) {
+    __shared__ __attribute__((aligned(16))) float wsh[32 * 64];
+    const int taps = a.KH * a.KW;
+    for (int i = threadIdx.x; i < taps * 64; i += 256) wsh[i] = a.w[i];
+    __syncthreads();
+    const int cq = threadIdx.x & 15;
+    const int c = cq * 4;
+    for (int m = blockIdx.x * 16 + (threadIdx.x >> 4); m < a.M; m += gridDim.x * 16) {
+        const uint32_t b = fd_div((uint32_t)m, a.fdHoWo);
+        const uint32_t rem = (uint32_t)m - b * a.fdHoWo.d;
+        const uint32_t ho = fd_div(rem, a.fdWo);
+        const uint32_t wo = rem - ho * a.fdWo.d;
+        const float* img = a.src + (size_t)b * a.H * a.W;
+        const int hi0 = (int)ho * a.sh - a.pt, wi0 = (int)wo * a.sw - a.pl;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int kh = 0; kh < a.KH; ++kh) {
+            const int hi = hi0 + kh;
+            if ((unsigned)hi >= (unsigned)a.H) continue;
+            for (int kw = 0; kw < a.KW; ++kw) {
+                const int wi = wi0 + kw;
+                if ((unsigned)wi >= (unsigned)a.W) continue;
+                const float x = img[hi * a.W + wi];
+                const float4 w = *reinterpret_cast<const float4*>(&wsh[(kh * a.KW + kw) * 64 + c]);
+                acc.x = fmaf(x, w.x, acc.x); acc.y = fmaf(x, w.y, acc.y);
+                acc.z = fmaf(x, w.z, acc.z); acc.w = fmaf(x, w.w, acc.w);
+            }
+        }
+        const int clip = a.img_clip ? a.img_clip[b] : 0;
+        const float4 cb = *reinterpret_cast<const float4*>(a.cb + (size_t)clip * a.cb_stride + c);
+        acc.x += cb.x; acc.y += cb.y; acc.z += cb.z; acc.w += cb.w;
+        if (a.ts) {
+            const float4 t = *reinterpret_cast<const float4*>(a.ts + ho * 64 + c);
+            acc.x += t.x; acc.y += t.y; acc.z += t.z; acc.w += t.w;
+        }
+        if (a.fs) {
+            const float4 f = *reinterpret_cast<const float4*>(a.fs + wo * 64 + c);
+            acc.x += f.x; acc.y += f.y; acc.z += f.z; acc.w += f.w;
+        }
+        if (a.relu) {
+            acc.x = fmaxf(acc.x, 0.f); acc.y = fmaxf(acc.y, 0.f);
+            acc.z = fmaxf(acc.z, 0.f); acc.w = fmaxf(acc.w, 0.f);
+        }
+        *reinterpret_cast<float4*>(a.out + (size_t)m * 64 + c) = acc;
+    }
+}
+
+void launch_direct_conv64(const DirectArgs& a, hipStream_t s) {
+    int grid = (a.M + 15) / 16;
+    if (grid > 256 * 16) grid = 256 * 16;
+    hipLaunchKernelGGL(direct_conv64, dim3(grid), dim3(256), 0, s, a);
+}
+
+// ---------------------------------------------------------------------------------------------
+__global__ void frame_index_kernel(const int64_t* off, int nclips, int64_t total, int* f_clip, int* f_t,
+                                   int* f_T) {
+    const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= total) return;
+    int lo = 0, hi = nclips;          // largest c with off[c] <= g
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (off[mid] <= g) lo = mid; else hi = mid;
+    }
+    f_clip[g] = lo;
+    f_t[g] = (int)(g - off[lo]);
+    f_T[g] = (int)(off[lo + 1] - off[lo]);
+}
+
+void launch_frame_index(const int64_t* frame_offsets_dev, int nclips, int64_t total, int* f_clip, int* f_t,
+                        int* f_T, hipStream_t s) {
+    if (total <= 0) return;
+    hipLaunchKernelGGL(frame_index_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s,
+                       frame_offsets_dev, nclips, total, f_clip, f_t, f_T);
+}
+
+// Sliding 35-frame windows (strided_crop, SN/apply.py:170-186,378): row h of frame g's window is
+// log-magnitude row t+h-17 of the same clip, or 0.0 (NOT the silence floor) outside [0, T).
+__global__ void __launch_bounds__(256) gather_windows_kernel(const float* logmag, const int* f_t,
+                                                             const int* f_T, int64_t g0, int n, float* xw) {
+    const int per = kMixWin * kBins;
+    const int64_t total = (int64_t)n * per;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int f = (int)(i / per);
+        const int r = (int)(i - (int64_t)f * per);
+        const int h = r / kBins, w = r - h * kBins;
+        const int64_t g = g0 + f;
+        const int tt = f_t[g] + h - kCenter;
+        xw[i] = (tt >= 0 && tt < f_T[g]) ? logmag[(g + h - kCenter) * kBins + w] : 0.f;
+    }
+}
+
+void launch_gather_windows(const float* logmag, const int* f_t, const int* f_T, int64_t g0, int n, float* xw,
+                           hipStream_t s) {
+    if (n <= 0) return;
+    int64_t blocks = ((int64_t)n * kMixWin * kBins + 255) / 256;
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    hipLaunchKernelGGL(gather_windows_kernel, dim3((unsigned)blocks), dim3(256), 0, s, logmag, f_t, f_T, g0, n, xw);
+}
+
+// ---------------------------------------------------------------------------------------------
+// tf.nn.avg_pool2d over the whole map (SN/main.py:199-202).  One block per (image, 64 channels);
+// fixed summation order -> deterministic.
+__global__ void __launch_bounds__(256) avgpool_kernel(const float* x, int HW, int C, float* out) {
+    __shared__ float part[4][64];
+    const int b = blockIdx.x, cg = blockIdx.y;
+    const int c = cg * 64 + (threadIdx.x & 63), p = threadIdx.x >> 6;
+    const float* base = x + (size_t)b * HW * C + c;
+    float s = 0.f;
+    for (int i = p; i < HW; i += 4) s += base[(size_t)i * C];
+    part[p][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (p == 0) {
+        const int l = threadIdx.x & 63;
+        out[(size_t)b * C + c] = (((part[0][l] + part[1][l]) + part[2][l]) + part[3][l]) / (float)HW;
+    }
+}
+
+void launch_avgpool(const float* x, int B, int HW, int C, float* out, hipStream_t s) {
+    if (B <= 0) return;
+    hipLaunchKernelGGL(avgpool_kernel, dim3(B, C / 64), dim3(256), 0, s, x, HW, C, out);
+}
+
+// ---------------------------------------------------------------------------------------------
+// All 16 conditioning projections of a clip at once (process_noise_t_f, SN/main.py:139-148), with
+// the BatchNorm scale/shift, conv bias and transform bias folded into Wc/base on the host.
+__global__ void __launch_bounds__(256) cond_kernel(const float* ea, const float* eb, const float* Wc,
+                                                   const float* base, int ncols, float* cb) {
+    __shared__ float e[2 * kEmb];
+    const int clip = blockIdx.x;
+    for (int i = threadIdx.x; i < kEmb; i += 256) {
+        e[i] = ea[(size_t)clip * kEmb + i];
+        e[kEmb + i] = eb[(size_t)clip * kEmb + i];
+    }
+    __syncthreads();
+    const int n = blockIdx.y * 256 + threadIdx.x;
+    if (n >= ncols) return;
+    float acc = base[n];
+    for (int k = 0; k < 2 * kEmb; ++k) acc = fmaf(e[k], Wc[(size_t)k * ncols + n], acc);
+    cb[(size_t)clip * ncols + n] = acc;
+}
+
+void launch_cond(const float* ea, const float* eb, int nclips, const float* Wc, const float* base, int ncols,
+                 float* cb, hipStream_t s) {
+    if (nclips <= 0) return;
+    hipLaunchKernelGGL(cond_kernel, dim3(nclips, (ncols + 255) / 256), dim3(256), 0, s, ea, eb, Wc, base, ncols, cb);
+}
+
+}  // namespace nhans

@@ -1,0 +1,779 @@
+// C ABI of libnhans_hip.so (see include/nhans_hip.h): context, folded-weight blob, workspace and
+// the launch sequences of the N-HANS hot path.
+#include "../../include/nhans_hip.h"
+#include "nhans_kernels.h"
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+using namespace nhans;
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string& msg) {
+    g_err = msg;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                          \
+    do {                                                                                       \
+        hipError_t e_ = (expr);                                                                \
+        if (e_ != hipSuccess)                                                                  \
+            return fail(NHANS_EHIP, std::string(#expr) + ": " + hipGetErrorString(e_));        \
+    } while (0)
+
+// ---- folded blob -----------------------------------------------------------------------------
+struct BlobHeader {
+    char magic[8];          // "NHANSFW1"
+    uint32_t version;
+    uint32_t n_entries;
+    uint64_t total_bytes;
+};
+struct BlobEntry {
+    char name[48];
+    uint64_t offset;        // bytes from blob start, 256-byte aligned
+    uint64_t nfloats;
+};
+
+struct BlockGeo {
+    int kh, kw, sh, sw, cin, cout, hin, win, hout, wout;
+};
+
+void same_pad(int n, int k, int s, int* out, int* before) {
+    *out = (n + s - 1) / s;
+    int total = std::max((*out - 1) * s + k - n, 0);
+    *before = total / 2;
+}
+
+std::vector<BlockGeo> tower_geometry() {       // SN/main.py:194-198
+    const int kh[4] = {8, 8, 4, 4}, kw[4] = {4, 4, 4, 4}, sh[4] = {3, 3, 1, 1}, sw[4] = {2, 2, 1, 2};
+    const int co[4] = {64, 128, 256, 512};
+    std::vector<BlockGeo> v;
+    int h = kCtxFrames, w = kBins, c = 1;
+    for (int i = 0; i < 4; ++i) {
+        BlockGeo g{kh[i], kw[i], sh[i], sw[i], c, co[i], h, w, (h + sh[i] - 1) / sh[i], (w + sw[i] - 1) / sw[i]};
+        v.push_back(g);
+        h = g.hout; w = g.wout; c = g.cout;
+    }
+    return v;
+}
+
+std::vector<BlockGeo> main_geometry() {        // SN/main.py:221-229
+    const int k[8] = {4, 4, 4, 4, 3, 3, 3, 3}, s[8] = {1, 1, 2, 1, 2, 1, 2, 1};
+    const int co[8] = {64, 64, 128, 128, 256, 256, 512, 512};
+    std::vector<BlockGeo> v;
+    int h = kMixWin, w = kBins, c = 1;
+    for (int i = 0; i < 8; ++i) {
+        BlockGeo g{k[i], k[i], s[i], s[i], c, co[i], h, w, (h + s[i] - 1) / s[i], (w + s[i] - 1) / s[i]};
+        v.push_back(g);
+        h = g.hout; w = g.wout; c = g.cout;
+    }
+    return v;
+}
+
+struct ProfEntry {
+    int calls = 0;
+    double flops = 0, bytes = 0;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+    double ms = 0;
+};
+
+}  // namespace
+
+struct nhans_ctx {
+    int kind = 0, device = 0;
+    float* blob_dev = nullptr;
+    size_t blob_bytes = 0;
+    std::map<std::string, const float*> arr;
+    std::map<std::string, size_t> arr_n;
+    std::vector<BlockGeo> tower, stack;
+    int cond_cols = 0;
+    std::vector<int> cond_off;      // column offset of conv j (= 2*block + {0,1})
+    // workspace
+    char* ws = nullptr;
+    size_t ws_bytes = 0, ws_top = 0;
+    int64_t frames_per_chunk = 1024;
+    int contexts_per_chunk = 64;
+    // pinned staging ring for the small host tables (offsets, block lists) copied per call
+    char* pin = nullptr;
+    size_t pin_bytes = (size_t)16 << 20, pin_top = 0;
+    // profiling
+    bool profile = false;
+    std::map<std::string, ProfEntry> prof;
+    std::vector<hipEvent_t> event_pool;
+
+    const float* A(const std::string& n) const {
+        auto it = arr.find(n);
+        return it == arr.end() ? nullptr : it->second;
+    }
+};
+
+namespace {
+
+int ws_reserve(nhans_ctx* c, size_t bytes) {
+    if (bytes <= c->ws_bytes) { c->ws_top = 0; return NHANS_OK; }
+    if (c->ws) { HIP_TRY(hipDeviceSynchronize()); HIP_TRY(hipFree(c->ws)); c->ws = nullptr; c->ws_bytes = 0; }
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&c->ws), bytes);
+    if (e != hipSuccess) {
+        char buf[128];
+        snprintf(buf, sizeof buf, "workspace hipMalloc(%zu bytes) failed: %s", bytes, hipGetErrorString(e));
+        return fail(NHANS_ENOMEM, buf);
+    }
+    c->ws_bytes = bytes;
+    c->ws_top = 0;
+    return NHANS_OK;
+}
+
+// Host -> device copy of a small table through the pinned ring, so the caller's (pageable, soon
+// destroyed) buffer is never the source of an in-flight asynchronous copy.
+int h2d(nhans_ctx* c, void* dst, const void* src, size_t bytes, hipStream_t s) {
+    if (bytes == 0) return NHANS_OK;
+    const size_t need = (bytes + 63) & ~(size_t)63;
+    if (need > c->pin_bytes) {
+        HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        return NHANS_OK;
+    }
+    if (c->pin_top + need > c->pin_bytes) {
+        HIP_TRY(hipStreamSynchronize(s));
+        c->pin_top = 0;
+    }
+    void* p = c->pin + c->pin_top;
+    c->pin_top += need;
+    std::memcpy(p, src, bytes);
+    HIP_TRY(hipMemcpyAsync(dst, p, bytes, hipMemcpyHostToDevice, s));
+    return NHANS_OK;
+}
+
+template <typename T> T* ws_take(nhans_ctx* c, size_t count) {
+    size_t bytes = (count * sizeof(T) + 255) & ~(size_t)255;
+    T* p = reinterpret_cast<T*>(c->ws + c->ws_top);
+    c->ws_top += bytes;
+    return p;
+}
+size_t ws_size(size_t count, size_t elem) { return (count * elem + 255) & ~(size_t)255; }
+
+// RAII-less profiling bracket around one launch
+struct Prof {
+    nhans_ctx* c;
+    hipStream_t s;
+    ProfEntry* e = nullptr;
+    hipEvent_t a{}, b{};
+    Prof(nhans_ctx* c_, hipStream_t s_, const char* name) : c(c_), s(s_) {
+        if (!c->profile) return;
+        e = &c->prof[name];
+        (void)hipEventCreate(&a);
+        (void)hipEventCreate(&b);
+        (void)hipEventRecord(a, s);
+    }
+    void done(double flops, double bytes) {
+        if (!e) return;
+        (void)hipEventRecord(b, s);
+        e->pending.emplace_back(a, b);
+        e->calls += 1;
+        e->flops += flops;
+        e->bytes += bytes;
+    }
+};
+
+void fill_epilogue_defaults(ConvArgs& a) {
+    a.img_clip = nullptr; a.ts = nullptr; a.fs = nullptr; a.id_mode = 0; a.id = nullptr; a.id_ld = 0;
+    a.idw = nullptr; a.idH = a.idW = 0; a.idsh = a.idsw = 1; a.relu = 1; a.aux = nullptr; a.aux_ld = 0;
+    a.cb_stride = 0;
+}
+
+ConvSeg make_seg(const float* src, const float* wpk, int H, int W, int C, int KH, int KW, int sh, int sw,
+                 bool same) {
+    ConvSeg g;
+    g.src = src; g.wpk = wpk; g.H = H; g.W = W; g.C = C; g.KH = KH; g.KW = KW; g.sh = sh; g.sw = sw;
+    int o, pb;
+    if (same) { same_pad(H, KH, sh, &o, &pb); g.pt = pb; same_pad(W, KW, sw, &o, &pb); g.pl = pb; }
+    else { g.pt = 0; g.pl = 0; }
+    g.nchunks = KH * KW * C / 32;
+    return g;
+}
+
+void set_out_geometry(ConvArgs& a, int B, int Ho, int Wo, int N, int Nreal, int ldo, float* out) {
+    a.Ho = Ho; a.Wo = Wo; a.M = B * Ho * Wo; a.N = N; a.Nreal = Nreal; a.ldo = ldo; a.out = out;
+    a.fdHoWo = make_fastdiv((uint32_t)(Ho * Wo));
+    a.fdWo = make_fastdiv((uint32_t)Wo);
+}
+
+void run_conv(nhans_ctx* c, const ConvArgs& a, hipStream_t s) {
+    Prof p(c, s, "conv_igemm_f32");
+    double fl = launch_conv_igemm(a, s);
+    p.done(fl, 0);
+}
+
+// ---- embedding tower for `n` context images already in HBM ----------------------------------
+int embed_impl(nhans_ctx* c, const float* ctx_lm, int n, float* emb_out, float* X, float* Ab, float* Y,
+               hipStream_t s) {
+    const auto& T = c->tower;
+    for (int i0 = 0; i0 < n; i0 += c->contexts_per_chunk) {
+        const int nc = std::min(c->contexts_per_chunk, n - i0);
+        const float* img = ctx_lm + (size_t)i0 * kCtxFrames * kBins;
+        float *x = X, *a1 = Ab, *y = Y;
+        for (int b = 0; b < 4; ++b) {
+            const BlockGeo& g = T[b];
+            const std::string p = "t" + std::to_string(b);
+            if (b == 0) {
+                DirectArgs d{};
+                d.src = img; d.w = c->A(p + ".c1.w"); d.H = g.hin; d.W = g.win; d.KH = g.kh; d.KW = g.kw;
+                d.sh = g.sh; d.sw = g.sw;
+                int o; same_pad(g.hin, g.kh, g.sh, &o, &d.pt); same_pad(g.win, g.kw, g.sw, &o, &d.pl);
+                d.Ho = g.hout; d.Wo = g.wout; d.M = nc * g.hout * g.wout; d.out = a1;
+                d.cb = c->A(p + ".c1.cb"); d.cb_stride = 0; d.img_clip = nullptr; d.ts = nullptr; d.fs = nullptr;
+                d.relu = 1; d.fdHoWo = make_fastdiv(g.hout * g.wout); d.fdWo = make_fastdiv(g.wout);
+                Prof pr(c, s, "direct_conv64");
+                launch_direct_conv64(d, s);
+                pr.done(2.0 * d.M * g.kh * g.kw * 64, 0);
+            } else {
+                ConvArgs a{};
+                fill_epilogue_defaults(a);
+                a.nseg = 1;
+                a.seg[0] = make_seg(x, c->A(p + ".c1.wpk"), g.hin, g.win, g.cin, g.kh, g.kw, g.sh, g.sw, true);
+                set_out_geometry(a, nc, g.hout, g.wout, g.cout, g.cout, g.cout, a1);
+                a.cb = c->A(p + ".c1.cb");
+                run_conv(c, a, s);
+            }
+            ConvArgs a{};
+            fill_epilogue_defaults(a);
+            a.nseg = 1;
+            a.seg[0] = make_seg(a1, c->A(p + ".c2.wpk"), g.hout, g.wout, g.cout, g.kh, g.kw, 1, 1, true);
+            if (b == 0) {
+                a.id_mode = 2; a.id = img; a.idH = g.hin; a.idW = g.win; a.idsh = g.sh; a.idsw = g.sw;
+                a.idw = c->A(p + ".c2.idw");
+            } else {
+                a.nseg = 2;
+                a.seg[1] = make_seg(x, c->A(p + ".c2.wpk_t"), g.hin, g.win, g.cin, 1, 1, g.sh, g.sw, false);
+            }
+            set_out_geometry(a, nc, g.hout, g.wout, g.cout, g.cout, g.cout, y);
+            a.cb = c->A(p + ".c2.cb");
+            run_conv(c, a, s);
+            std::swap(x, y);
+        }
+        const BlockGeo& g = T[3];
+        Prof pr(c, s, "avgpool");
+        launch_avgpool(x, nc, g.hout * g.wout, g.cout, emb_out + (size_t)i0 * kEmb, s);
+        pr.done(0, (double)nc * g.hout * g.wout * g.cout * 4);
+    }
+    return NHANS_OK;
+}
+
+size_t tower_buf_floats(const nhans_ctx* c) {
+    size_t m = 0;
+    for (const auto& g : c->tower) m = std::max(m, (size_t)g.hout * g.wout * g.cout);
+    return m * (size_t)c->contexts_per_chunk;
+}
+size_t stack_buf_floats(const nhans_ctx* c, int64_t wf) {
+    size_t m = 0;
+    for (const auto& g : c->stack) m = std::max(m, (size_t)g.hout * g.wout * g.cout);
+    return m * (size_t)wf;
+}
+
+// ---- conditioned stack + head ---------------------------------------------------------------
+struct StackBufs {
+    int* f_clip; int* f_t; int* f_T; int64_t* foff_dev; float* cb_all;
+    float* xw; float* X; float* A; float* Y;
+};
+
+size_t stack_ws_bytes(const nhans_ctx* c, int64_t total, int nclips, int64_t wf) {
+    size_t b = 3 * ws_size(total, 4) + ws_size(nclips + 1, 8) + ws_size((size_t)nclips * c->cond_cols, 4);
+    b += ws_size((size_t)wf * kMixWin * kBins, 4) + 3 * ws_size(stack_buf_floats(c, wf), 4);
+    return b;
+}
+
+void stack_take(nhans_ctx* c, int64_t total, int nclips, int64_t wf, StackBufs* sb) {
+    sb->f_clip = ws_take<int>(c, total); sb->f_t = ws_take<int>(c, total); sb->f_T = ws_take<int>(c, total);
+    sb->foff_dev = ws_take<int64_t>(c, nclips + 1);
+    sb->cb_all = ws_take<float>(c, (size_t)nclips * c->cond_cols);
+    sb->xw = ws_take<float>(c, (size_t)wf * kMixWin * kBins);
+    const size_t nb = stack_buf_floats(c, wf);
+    sb->X = ws_take<float>(c, nb); sb->A = ws_take<float>(c, nb); sb->Y = ws_take<float>(c, nb);
+}
+
+// Runs blocks [0, upto) for frames [g0, g0+n); returns the buffer holding the last output.
+// upto = 8: whole stack; upto = 9: + last_conv (output in sb.A).
+float* run_stack_chunk(nhans_ctx* c, const float* logmag, const StackBufs& sb, int64_t g0, int n, int upto,
+                       hipStream_t s) {
+    {
+        Prof pr(c, s, "gather_windows");
+        launch_gather_windows(logmag, sb.f_t, sb.f_T, g0, n, sb.xw, s);
+        pr.done(0, (double)n * kMixWin * kBins * 8);
+    }
+    float *x = sb.X, *a1 = sb.A, *y = sb.Y;
+    const int* clipmap = sb.f_clip + g0;
+    for (int b = 0; b < 8 && b < upto; ++b) {
+        const BlockGeo& g = c->stack[b];
+        const std::string p = "m" + std::to_string(b);
+        const float* cb1 = sb.cb_all + c->cond_off[2 * b];
+        const float* cb2 = sb.cb_all + c->cond_off[2 * b + 1];
+        if (b == 0) {
+            DirectArgs d{};
+            d.src = sb.xw; d.w = c->A(p + ".c1.w"); d.H = g.hin; d.W = g.win; d.KH = g.kh; d.KW = g.kw;
+            d.sh = 1; d.sw = 1;
+            int o; same_pad(g.hin, g.kh, 1, &o, &d.pt); same_pad(g.win, g.kw, 1, &o, &d.pl);
+            d.Ho = g.hout; d.Wo = g.wout; d.M = n * g.hout * g.wout; d.out = a1;
+            d.cb = cb1; d.cb_stride = c->cond_cols; d.img_clip = clipmap;
+            d.ts = c->A(p + ".c1.ts"); d.fs = c->A(p + ".c1.fs"); d.relu = 1;
+            d.fdHoWo = make_fastdiv(g.hout * g.wout); d.fdWo = make_fastdiv(g.wout);
+            Prof pr(c, s, "direct_conv64");
+            launch_direct_conv64(d, s);
+            pr.done(2.0 * d.M * g.kh * g.kw * 64, 0);
+        } else {
+            ConvArgs a{};
+            fill_epilogue_defaults(a);
+            a.nseg = 1;
+            a.seg[0] = make_seg(x, c->A(p + ".c1.wpk"), g.hin, g.win, g.cin, g.kh, g.kw, g.sh, g.sw, true);
+            set_out_geometry(a, n, g.hout, g.wout, g.cout, g.cout, g.cout, a1);
+            a.cb = cb1; a.cb_stride = c->cond_cols; a.img_clip = clipmap;
+            a.ts = c->A(p + ".c1.ts"); a.fs = c->A(p + ".c1.fs");
+            run_conv(c, a, s);
+        }
+        ConvArgs a{};
+        fill_epilogue_defaults(a);
+        a.nseg = 1;
+        a.seg[0] = make_seg(a1, c->A(p + ".c2.wpk"), g.hout, g.wout, g.cout, g.kh, g.kw, 1, 1, true);
+        a.cb = cb2; a.cb_stride = c->cond_cols; a.img_clip = clipmap;
+        a.ts = c->A(p + ".c2.ts"); a.fs = c->A(p + ".c2.fs");
+        a.idw = c->A(p + ".c2.idw");
+        float* out;
+        if (b == 0) {                       // 1 -> 64 transform on the window image itself
+            a.id_mode = 2; a.id = sb.xw; a.idH = g.hin; a.idW = g.win; a.idsh = 1; a.idsw = 1;
+            out = x;
+        } else if (g.cin == g.cout) {       // identity shortcut, written in place over the block input
+            a.id_mode = 1; a.id = x; a.id_ld = g.cout;
+            out = x;
+        } else {                            // 1x1 strided transform as extra K columns
+            a.nseg = 2;
+            a.seg[1] = make_seg(x, c->A(p + ".c2.wpk_t"), g.hin, g.win, g.cin, 1, 1, g.sh, g.sw, false);
+            out = y;
+        }
+        set_out_geometry(a, n, g.hout, g.wout, g.cout, g.cout, g.cout, out);
+        run_conv(c, a, s);
+        if (out == y) std::swap(x, y);
+    }
+    if (upto >= 9) {                        // last_conv [5,1] VALID + BN + ReLU  (SN/main.py:232-236)
+        const BlockGeo& g = c->stack[7];
+        ConvArgs a{};
+        fill_epilogue_defaults(a);
+        a.nseg = 1;
+        a.seg[0] = make_seg(x, c->A("head.conv.wpk"), g.hout, g.wout, g.cout, g.hout, 1, 1, 1, false);
+        set_out_geometry(a, n, 1, g.wout, 512, 512, 512, a1);
+        a.cb = c->A("head.conv.cb");
+        run_conv(c, a, s);
+        return a1;
+    }
+    return x;
+}
+
+int mask_net_impl(nhans_ctx* c, const float* logmag, const int64_t* foff, int nclips, const float* ea,
+                  const float* eb, float* logits, float* denoised, const StackBufs& sb, int64_t wf,
+                  hipStream_t s) {
+    const int64_t total = foff[nclips];
+    { int rc = h2d(c, sb.foff_dev, foff, (nclips + 1) * sizeof(int64_t), s); if (rc) return rc; }
+    launch_frame_index(sb.foff_dev, nclips, total, sb.f_clip, sb.f_t, sb.f_T, s);
+    {
+        Prof pr(c, s, "cond_proj");
+        launch_cond(ea, eb, nclips, c->A("cond.w"), c->A("cond.base"), c->cond_cols, sb.cb_all, s);
+        pr.done(2.0 * nclips * 2 * kEmb * c->cond_cols, 0);
+    }
+    const BlockGeo& g = c->stack[7];
+    for (int64_t g0 = 0; g0 < total; g0 += wf) {
+        const int n = (int)std::min<int64_t>(wf, total - g0);
+        float* hc = run_stack_chunk(c, logmag, sb, g0, n, 9, s);
+        // last_dense 13312 -> 201 (+bias) and denoised = mixed_central + out  (SN/main.py:237-242)
+        ConvArgs a{};
+        fill_epilogue_defaults(a);
+        a.nseg = 1;
+        a.seg[0] = make_seg(hc, c->A("head.dense.wpk"), 1, 1, g.wout * 512, 1, 1, 1, 1, false);
+        set_out_geometry(a, n, 1, 1, 256, kBins, kBins, denoised + g0 * kBins);
+        a.cb = c->A("head.dense.cb");
+        a.relu = 0;
+        a.id_mode = 1; a.id = logmag + g0 * kBins; a.id_ld = kBins; a.idw = c->A("head.dense.idw");
+        if (logits) { a.aux = logits + g0 * kBins; a.aux_ld = kBins; }
+        run_conv(c, a, s);
+    }
+    return NHANS_OK;
+}
+
+// ---- STFT / iSTFT host-side block tables ----------------------------------------------------
+struct HostTables {
+    std::vector<int64_t> soff, foff, ooff;
+    std::vector<int> bclip, bpos;
+};
+
+int stft_impl(nhans_ctx* c, const float* wav, const int64_t* soff, int nclips, int maxf, float* logmag,
+              float* phase, int64_t* dev_tables /*3*(nclips+1)*/, int* dev_blocks, std::vector<int64_t>* foff_out,
+              hipStream_t s) {
+    std::vector<int64_t> foff(nclips + 1, 0);
+    std::vector<int> bclip, bf0;
+    for (int i = 0; i < nclips; ++i) {
+        int64_t t = nhans_num_frames(soff[i + 1] - soff[i]);
+        if (maxf > 0) {
+            if (t < maxf) return fail(NHANS_ESHORT, "conditioning clip " + std::to_string(i) + " has " +
+                                      std::to_string(t) + " frames; " + std::to_string(maxf) + " needed");
+            t = maxf;
+        }
+        foff[i + 1] = foff[i] + t;
+        for (int f0 = 0; f0 < t; f0 += kStftFramesPerBlock) { bclip.push_back(i); bf0.push_back(f0); }
+    }
+    const int nb = (int)bclip.size();
+    int rc = h2d(c, dev_tables, soff, (nclips + 1) * 8, s); if (rc) return rc;
+    rc = h2d(c, dev_tables + (nclips + 1), foff.data(), (nclips + 1) * 8, s); if (rc) return rc;
+    rc = h2d(c, dev_blocks, bclip.data(), (size_t)nb * 4, s); if (rc) return rc;
+    rc = h2d(c, dev_blocks + nb, bf0.data(), (size_t)nb * 4, s); if (rc) return rc;
+    ClipTable t{dev_tables, dev_tables + (nclips + 1), nullptr};
+    Prof pr(c, s, "stft_features");
+    launch_stft(wav, t, dev_blocks, dev_blocks + nb, nb, c->A("tw400"), c->A("window"), logmag, phase, s);
+    pr.done(0, (double)foff[nclips] * (kHop * 4 + (phase ? 2 : 1) * kBins * 4));
+    if (foff_out) *foff_out = foff;
+    return NHANS_OK;
+}
+
+size_t stft_blocks(const int64_t* soff, int nclips, int maxf) {
+    size_t nb = 0;
+    for (int i = 0; i < nclips; ++i) {
+        int64_t t = nhans_num_frames(soff[i + 1] - soff[i]);
+        if (maxf > 0 && t > maxf) t = maxf;
+        nb += (size_t)((t + kStftFramesPerBlock - 1) / kStftFramesPerBlock);
+    }
+    return nb;
+}
+
+int istft_impl(nhans_ctx* c, const float* logmag, const float* phase, const int64_t* foff, int nclips,
+               const int64_t* ooff, float* wav_out, int64_t* dev_tables, int* dev_blocks, hipStream_t s) {
+    std::vector<int> bclip, bh0;
+    for (int i = 0; i < nclips; ++i) {
+        const int64_t t = foff[i + 1] - foff[i];
+        if (t <= 0) continue;
+        for (int h0 = 0; h0 < t + 2; h0 += kIstftHopsPerBlock) { bclip.push_back(i); bh0.push_back(h0); }
+    }
+    const int nb = (int)bclip.size();
+    int rc = h2d(c, dev_tables, foff, (nclips + 1) * 8, s); if (rc) return rc;
+    rc = h2d(c, dev_tables + (nclips + 1), ooff, (nclips + 1) * 8, s); if (rc) return rc;
+    rc = h2d(c, dev_blocks, bclip.data(), (size_t)nb * 4, s); if (rc) return rc;
+    rc = h2d(c, dev_blocks + nb, bh0.data(), (size_t)nb * 4, s); if (rc) return rc;
+    ClipTable t{nullptr, dev_tables, dev_tables + (nclips + 1)};
+    Prof pr(c, s, "istft_ola");
+    launch_istft(logmag, phase, t, dev_blocks, dev_blocks + nb, nb, c->A("tw400"), c->A("wsyn"), wav_out, s);
+    pr.done(0, (double)foff[nclips] * (kHop * 4 + 2 * kBins * 4));
+    return NHANS_OK;
+}
+
+size_t istft_blocks(const int64_t* foff, int nclips) {
+    size_t nb = 0;
+    for (int i = 0; i < nclips; ++i) {
+        const int64_t t = foff[i + 1] - foff[i];
+        if (t > 0) nb += (size_t)((t + 2 + kIstftHopsPerBlock - 1) / kIstftHopsPerBlock);
+    }
+    return nb;
+}
+
+int check_ctx(nhans_ctx* c) {
+    if (!c) return fail(NHANS_EINVAL, "null context");
+    hipError_t e = hipSetDevice(c->device);
+    if (e != hipSuccess) return fail(NHANS_EHIP, std::string("hipSetDevice: ") + hipGetErrorString(e));
+    return NHANS_OK;
+}
+
+}  // namespace
+
+// ================================================================================================
+extern "C" {
+
+int nhans_abi_version(void) { return NHANS_ABI_VERSION; }
+const char* nhans_last_error(void) { return g_err.c_str(); }
+
+int64_t nhans_num_frames(int64_t n) { return n < kWin ? 0 : 1 + (n - kWin) / kHop; }
+
+int nhans_create(int model_kind, const void* blob, size_t nbytes, int device_id, nhans_ctx** out) {
+    if (!out || !blob) return fail(NHANS_EINVAL, "null argument");
+    *out = nullptr;
+    if (model_kind != NHANS_DENOISER && model_kind != NHANS_SEPARATOR) return fail(NHANS_EINVAL, "bad model_kind");
+    if (nbytes < sizeof(BlobHeader)) return fail(NHANS_EINVAL, "blob too short");
+    const BlobHeader* h = static_cast<const BlobHeader*>(blob);
+    if (std::memcmp(h->magic, "NHANSFW1", 8) != 0 || h->version != 1) return fail(NHANS_EINVAL, "bad blob magic/version");
+    if (h->total_bytes != nbytes || sizeof(BlobHeader) + (size_t)h->n_entries * sizeof(BlobEntry) > nbytes)
+        return fail(NHANS_EINVAL, "blob size mismatch");
+    HIP_TRY(hipSetDevice(device_id));
+    nhans_ctx* c = new nhans_ctx();
+    c->kind = model_kind;
+    c->device = device_id;
+    c->tower = tower_geometry();
+    c->stack = main_geometry();
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&c->blob_dev), nbytes);
+    if (e != hipSuccess) { delete c; return fail(NHANS_ENOMEM, "hipMalloc for weights failed"); }
+    c->blob_bytes = nbytes;
+    e = hipMemcpy(c->blob_dev, blob, nbytes, hipMemcpyHostToDevice);
+    if (e != hipSuccess) { nhans_destroy(c); return fail(NHANS_EHIP, "weight upload failed"); }
+    e = hipHostMalloc(reinterpret_cast<void**>(&c->pin), c->pin_bytes, hipHostMallocDefault);
+    if (e != hipSuccess) { nhans_destroy(c); return fail(NHANS_ENOMEM, "pinned staging allocation failed"); }
+    const BlobEntry* ent = reinterpret_cast<const BlobEntry*>(static_cast<const char*>(blob) + sizeof(BlobHeader));
+    for (uint32_t i = 0; i < h->n_entries; ++i) {
+        if (ent[i].offset % 16 || ent[i].offset + ent[i].nfloats * 4 > nbytes) {
+            nhans_destroy(c); return fail(NHANS_EINVAL, "blob entry out of range");
+        }
+        std::string name(ent[i].name, strnlen(ent[i].name, sizeof ent[i].name));
+        c->arr[name] = reinterpret_cast<const float*>(reinterpret_cast<const char*>(c->blob_dev) + ent[i].offset);
+        c->arr_n[name] = ent[i].nfloats;
+    }
+    // conditioning columns: conv order m0.c1, m0.c2, m1.c1, ...
+    int off = 0;
+    for (int b = 0; b < 8; ++b) for (int j = 0; j < 2; ++j) { c->cond_off.push_back(off); off += c->stack[b].cout; }
+    c->cond_cols = off;
+    // every array the launch sequences will dereference must be present with the right size
+    std::vector<std::pair<std::string, size_t>> need = {
+        {"tw400", 800}, {"window", 400}, {"wsyn", 400},
+        {"cond.w", (size_t)2 * kEmb * off}, {"cond.base", (size_t)off},
+        {"head.conv.wpk", (size_t)5 * 512 * 512}, {"head.conv.cb", 512},
+        {"head.dense.wpk", (size_t)26 * 512 * 256}, {"head.dense.cb", 256}, {"head.dense.idw", 256}};
+    for (int b = 0; b < 4; ++b) {
+        const BlockGeo& g = c->tower[b];
+        const std::string p = "t" + std::to_string(b);
+        const size_t k2 = (size_t)g.kh * g.kw * g.cout * g.cout;
+        if (b == 0) { need.push_back({p + ".c1.w", (size_t)g.kh * g.kw * 64}); need.push_back({p + ".c2.idw", (size_t)g.cout}); }
+        else { need.push_back({p + ".c1.wpk", (size_t)g.kh * g.kw * g.cin * g.cout}); need.push_back({p + ".c2.wpk_t", (size_t)g.cin * g.cout}); }
+        need.push_back({p + ".c1.cb", (size_t)g.cout});
+        need.push_back({p + ".c2.wpk", k2});
+        need.push_back({p + ".c2.cb", (size_t)g.cout});
+    }
+    for (int b = 0; b < 8; ++b) {
+        const BlockGeo& g = c->stack[b];
+        const std::string p = "m" + std::to_string(b);
+        if (b == 0) need.push_back({p + ".c1.w", (size_t)g.kh * g.kw * 64});
+        else need.push_back({p + ".c1.wpk", (size_t)g.kh * g.kw * g.cin * g.cout});
+        need.push_back({p + ".c2.wpk", (size_t)g.kh * g.kw * g.cout * g.cout});
+        if (b > 0 && g.cin != g.cout) need.push_back({p + ".c2.wpk_t", (size_t)g.cin * g.cout});
+        need.push_back({p + ".c2.idw", (size_t)g.cout});
+        for (const char* cv : {".c1", ".c2"}) {
+            need.push_back({p + cv + ".ts", (size_t)g.hout * g.cout});
+            need.push_back({p + cv + ".fs", (size_t)g.wout * g.cout});
+        }
+    }
+    for (const auto& kv : need) {
+        auto it = c->arr_n.find(kv.first);
+        if (it == c->arr_n.end() || it->second != kv.second) {
+            std::string msg = "folded blob: array '" + kv.first + "' missing or wrong size (want " +
+                              std::to_string(kv.second) + ")";
+            nhans_destroy(c);
+            return fail(NHANS_EINVAL, msg);
+        }
+    }
+    *out = c;
+    return NHANS_OK;
+}
+
+void nhans_destroy(nhans_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipDeviceSynchronize();
+    for (auto& kv : c->prof)
+        for (auto& ev : kv.second.pending) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
+    if (c->ws) (void)hipFree(c->ws);
+    if (c->pin) (void)hipHostFree(c->pin);
+    if (c->blob_dev) (void)hipFree(c->blob_dev);
+    delete c;
+}
+
+int nhans_set_option(nhans_ctx* c, const char* key, int64_t value) {
+    if (!c || !key) return fail(NHANS_EINVAL, "null argument");
+    const std::string k(key);
+    if (k == "frames_per_chunk") { if (value < 1) return fail(NHANS_EINVAL, "frames_per_chunk < 1"); c->frames_per_chunk = value; }
+    else if (k == "contexts_per_chunk") { if (value < 1) return fail(NHANS_EINVAL, "contexts_per_chunk < 1"); c->contexts_per_chunk = (int)value; }
+    else if (k == "profile") c->profile = value != 0;
+    else return fail(NHANS_EINVAL, "unknown option " + k);
+    return NHANS_OK;
+}
+
+size_t nhans_workspace_bytes(nhans_ctx* c, int64_t total_frames, int nclips) {
+    if (!c) return 0;
+    const int64_t wf = std::min<int64_t>(c->frames_per_chunk, std::max<int64_t>(total_frames, 1));
+    size_t b = stack_ws_bytes(c, total_frames, nclips, wf);
+    b = std::max(b, 3 * ws_size(tower_buf_floats(c), 4));
+    b += 4 * ws_size((size_t)total_frames * kBins, 4);                       // logmag, phase, denoised, logits
+    b += ws_size((size_t)2 * nclips * kCtxFrames * kBins, 4) + ws_size((size_t)2 * nclips * kEmb, 4);
+    b += 1 << 20;
+    return b;
+}
+
+int nhans_stft_features(nhans_ctx* c, const float* wav, const int64_t* soff, int nclips, int maxf,
+                        float* logmag, float* phase, void* stream) {
+    int rc = check_ctx(c); if (rc) return rc;
+    if (!wav || !soff || !logmag || nclips < 0) return fail(NHANS_EINVAL, "null argument");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const size_t nb = stft_blocks(soff, nclips, maxf);
+    rc = ws_reserve(c, ws_size(2 * (nclips + 1), 8) + ws_size(2 * nb, 4)); if (rc) return rc;
+    int64_t* tabs = ws_take<int64_t>(c, 2 * (nclips + 1));
+    int* blocks = ws_take<int>(c, 2 * nb);
+    return stft_impl(c, wav, soff, nclips, maxf, logmag, phase, tabs, blocks, nullptr, s);
+}
+
+int nhans_embed(nhans_ctx* c, const float* ctx_lm, int n, float* emb_out, void* stream) {
+    int rc = check_ctx(c); if (rc) return rc;
+    if (!ctx_lm || !emb_out || n < 0) return fail(NHANS_EINVAL, "null argument");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const size_t nb = tower_buf_floats(c);
+    rc = ws_reserve(c, 3 * ws_size(nb, 4)); if (rc) return rc;
+    float* X = ws_take<float>(c, nb); float* A = ws_take<float>(c, nb); float* Y = ws_take<float>(c, nb);
+    return embed_impl(c, ctx_lm, n, emb_out, X, A, Y, s);
+}
+
+int nhans_mask_net(nhans_ctx* c, const float* logmag, const int64_t* foff, int nclips, const float* ea,
+                   const float* eb, float* logits, float* denoised, void* stream) {
+    int rc = check_ctx(c); if (rc) return rc;
+    if (!logmag || !foff || !ea || !eb || !denoised || nclips < 1) return fail(NHANS_EINVAL, "null argument");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int64_t total = foff[nclips];
+    if (total <= 0) return NHANS_OK;
+    const int64_t wf = std::min<int64_t>(c->frames_per_chunk, total);
+    rc = ws_reserve(c, stack_ws_bytes(c, total, nclips, wf)); if (rc) return rc;
+    StackBufs sb;
+    stack_take(c, total, nclips, wf, &sb);
+    return mask_net_impl(c, logmag, foff, nclips, ea, eb, logits, denoised, sb, wf, s);
+}
+
+int nhans_debug_block_output(nhans_ctx* c, const float* logmag, const int64_t* foff, int nclips, const float* ea,
+                             const float* eb, int64_t frame0, int nframes, int block, float* out, void* stream) {
+    int rc = check_ctx(c); if (rc) return rc;
+    if (!logmag || !foff || !ea || !eb || !out || block < 0 || block > 8) return fail(NHANS_EINVAL, "bad argument");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int64_t total = foff[nclips];
+    if (frame0 < 0 || frame0 + nframes > total) return fail(NHANS_EINVAL, "frame range outside batch");
+    rc = ws_reserve(c, stack_ws_bytes(c, total, nclips, nframes)); if (rc) return rc;
+    StackBufs sb;
+    stack_take(c, total, nclips, nframes, &sb);
+    rc = h2d(c, sb.foff_dev, foff, (nclips + 1) * sizeof(int64_t), s); if (rc) return rc;
+    launch_frame_index(sb.foff_dev, nclips, total, sb.f_clip, sb.f_t, sb.f_T, s);
+    launch_cond(ea, eb, nclips, c->A("cond.w"), c->A("cond.base"), c->cond_cols, sb.cb_all, s);
+    const float* res = run_stack_chunk(c, logmag, sb, frame0, nframes, block + 1, s);
+    size_t per;
+    if (block == 8) per = (size_t)26 * 512;
+    else per = (size_t)c->stack[block].hout * c->stack[block].wout * c->stack[block].cout;
+    HIP_TRY(hipMemcpyAsync(out, res, per * nframes * 4, hipMemcpyDeviceToDevice, s));
+    return NHANS_OK;
+}
+
+int nhans_istft(nhans_ctx* c, const float* logmag, const float* phase, const int64_t* foff, int nclips,
+                const int64_t* ooff, float* wav_out, void* stream) {
+    int rc = check_ctx(c); if (rc) return rc;
+    if (!logmag || !phase || !foff || !ooff || !wav_out) return fail(NHANS_EINVAL, "null argument");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const size_t nb = istft_blocks(foff, nclips);
+    rc = ws_reserve(c, ws_size(2 * (nclips + 1), 8) + ws_size(2 * nb, 4)); if (rc) return rc;
+    int64_t* tabs = ws_take<int64_t>(c, 2 * (nclips + 1));
+    int* blocks = ws_take<int>(c, 2 * nb);
+    return istft_impl(c, logmag, phase, foff, nclips, ooff, wav_out, tabs, blocks, s);
+}
+
+int nhans_enhance_clips(nhans_ctx* c, const float* mix, const int64_t* moff, int nclips, const float* ca,
+                        const int64_t* caoff, const float* cbw, const int64_t* cboff, float* den_wav,
+                        float* mixed_wav, float* logmag_out, float* phase_out, float* logits_out, float* emb_out,
+                        void* stream) {
+    int rc = check_ctx(c); if (rc) return rc;
+    if (!mix || !moff || !ca || !caoff || !cbw || !cboff || !den_wav || nclips < 1)
+        return fail(NHANS_EINVAL, "null argument");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    std::vector<int64_t> foff(nclips + 1, 0);
+    for (int i = 0; i < nclips; ++i) {
+        const int64_t n = moff[i + 1] - moff[i];
+        if (n >= kWin && (n - kWin) % kHop != 0)
+            return fail(NHANS_EINVAL, "mixture clip " + std::to_string(i) + " is not trimmed to a whole frame count");
+        foff[i + 1] = foff[i] + nhans_num_frames(n);
+    }
+    const int64_t total = foff[nclips];
+    const int64_t wf = std::min<int64_t>(c->frames_per_chunk, std::max<int64_t>(total, 1));
+    // workspace plan
+    const size_t nb_mix = stft_blocks(moff, nclips, 0), nb_ca = stft_blocks(caoff, nclips, kCtxFrames),
+                 nb_cb = stft_blocks(cboff, nclips, kCtxFrames), nb_is = istft_blocks(foff.data(), nclips);
+    const size_t nblk = std::max(std::max(nb_mix, nb_ca), std::max(nb_cb, nb_is));
+    size_t bytes = 4 * ws_size((size_t)total * kBins, 4) + ws_size((size_t)2 * nclips * kCtxFrames * kBins, 4) +
+                   ws_size((size_t)2 * nclips * kEmb, 4) + 4 * ws_size(2 * (nclips + 1), 8) + 4 * ws_size(2 * nblk, 4);
+    bytes += std::max(stack_ws_bytes(c, total, nclips, wf), 3 * ws_size(tower_buf_floats(c), 4));
+    rc = ws_reserve(c, bytes); if (rc) return rc;
+    float* lm = ws_take<float>(c, (size_t)total * kBins);
+    float* ph = ws_take<float>(c, (size_t)total * kBins);
+    float* den = ws_take<float>(c, (size_t)total * kBins);
+    float* lg = ws_take<float>(c, (size_t)total * kBins);
+    float* ctxlm = ws_take<float>(c, (size_t)2 * nclips * kCtxFrames * kBins);
+    float* emb = ws_take<float>(c, (size_t)2 * nclips * kEmb);
+    int64_t* tabs[4]; int* blks[4];
+    for (int i = 0; i < 4; ++i) { tabs[i] = ws_take<int64_t>(c, 2 * (nclips + 1)); blks[i] = ws_take<int>(c, 2 * nblk); }
+    const size_t mark = c->ws_top;
+
+    rc = stft_impl(c, mix, moff, nclips, 0, lm, ph, tabs[0], blks[0], nullptr, s); if (rc) return rc;
+    rc = stft_impl(c, ca, caoff, nclips, kCtxFrames, ctxlm, nullptr, tabs[1], blks[1], nullptr, s); if (rc) return rc;
+    rc = stft_impl(c, cbw, cboff, nclips, kCtxFrames, ctxlm + (size_t)nclips * kCtxFrames * kBins, nullptr, tabs[2],
+                   blks[2], nullptr, s);
+    if (rc) return rc;
+    {
+        const size_t nb = tower_buf_floats(c);
+        float* X = ws_take<float>(c, nb); float* A = ws_take<float>(c, nb); float* Y = ws_take<float>(c, nb);
+        rc = embed_impl(c, ctxlm, 2 * nclips, emb, X, A, Y, s); if (rc) return rc;
+    }
+    if (total > 0) {
+        c->ws_top = mark;
+        StackBufs sb;
+        stack_take(c, total, nclips, wf, &sb);
+        rc = mask_net_impl(c, lm, foff.data(), nclips, emb, emb + (size_t)nclips * kEmb, lg, den, sb, wf, s);
+        if (rc) return rc;
+        rc = istft_impl(c, den, ph, foff.data(), nclips, moff, den_wav, tabs[3], blks[3], s); if (rc) return rc;
+        if (mixed_wav) {
+            // tabs/blks[3] are reused: same stream, so the first launch has consumed them in order
+            rc = istft_impl(c, lm, ph, foff.data(), nclips, moff, mixed_wav, tabs[3], blks[3], s); if (rc) return rc;
+        }
+        if (logmag_out) HIP_TRY(hipMemcpyAsync(logmag_out, lm, (size_t)total * kBins * 4, hipMemcpyDeviceToDevice, s));
+        if (phase_out) HIP_TRY(hipMemcpyAsync(phase_out, ph, (size_t)total * kBins * 4, hipMemcpyDeviceToDevice, s));
+        if (logits_out) HIP_TRY(hipMemcpyAsync(logits_out, lg, (size_t)total * kBins * 4, hipMemcpyDeviceToDevice, s));
+    }
+    if (emb_out) HIP_TRY(hipMemcpyAsync(emb_out, emb, (size_t)2 * nclips * kEmb * 4, hipMemcpyDeviceToDevice, s));
+    return NHANS_OK;
+}
+
+int nhans_profile_reset(nhans_ctx* c) {
+    if (!c) return fail(NHANS_EINVAL, "null context");
+    (void)hipSetDevice(c->device);
+    (void)hipDeviceSynchronize();
+    for (auto& kv : c->prof)
+        for (auto& ev : kv.second.pending) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
+    c->prof.clear();
+    return NHANS_OK;
+}
+
+int nhans_profile_json(nhans_ctx* c, char* buf, size_t buflen) {
+    if (!c) return fail(NHANS_EINVAL, "null context");
+    (void)hipSetDevice(c->device);
+    std::string js = "{";
+    bool first = true;
+    for (auto& kv : c->prof) {
+        ProfEntry& e = kv.second;
+        for (auto& ev : e.pending) {
+            (void)hipEventSynchronize(ev.second);
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, ev.first, ev.second) == hipSuccess) e.ms += ms;
+            (void)hipEventDestroy(ev.first);
+            (void)hipEventDestroy(ev.second);
+        }
+        e.pending.clear();
+        char line[256];
+        snprintf(line, sizeof line, "%s\"%s\": {\"calls\": %d, \"ms\": %.6f, \"flops\": %.6e, \"bytes\": %.6e}",
+                 first ? "" : ", ", kv.first.c_str(), e.calls, e.ms, e.flops, e.bytes);
+        js += line;
+        first = false;
+    }
+    js += "}";
+    if (buf && buflen) {
+        const size_t n = std::min(buflen - 1, js.size());
+        std::memcpy(buf, js.data(), n);
+        buf[n] = 0;
+    }
+    return (int)js.size();
+}
+
+}  // extern "C"

@@ -1,0 +1,121 @@
+// Internal declarations shared by the HIP translation units of libnhans_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace nhans {
+
+constexpr int kWin = 400, kHop = 160, kBins = 201, kMixWin = 35, kCtxFrames = 200, kEmb = 512;
+constexpr int kCenter = kMixWin / 2;
+
+// Division by a runtime constant for numerators < 2^31 (Granlund-Montgomery round-up form).
+struct FastDiv {
+    uint32_t d, mul, sh;
+};
+inline FastDiv make_fastdiv(uint32_t d) {
+    FastDiv f;
+    f.d = d;
+    uint32_t l = 0;
+    while ((1ull << l) < d) ++l;
+    f.mul = (uint32_t)((((uint64_t)1 << 32) * (((uint64_t)1 << l) - d)) / d + 1);
+    f.sh = l;
+    return f;
+}
+__device__ __forceinline__ uint32_t fd_div(uint32_t n, const FastDiv& f) {
+    return (__umulhi(f.mul, n) + n) >> f.sh;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Implicit-GEMM convolution on the f32 matrix cores (conv_igemm.hip).
+//   out[m, n] = epilogue( sum_seg sum_{kh,kw,c} src_seg[b, ho*sh+kh-pt, wo*sw+kw-pl, c] * W_seg[kh,kw,c,n] )
+// with m = (b*Ho + ho)*Wo + wo.  Up to two K segments: the kxk taps of the block's main conv and
+// (for blocks that change channel count) the 1x1 strided `_transform` conv folded in as extra K.
+struct ConvSeg {
+    const float* src;   // NHWC [B, H, W, C]
+    const float* wpk;   // packed weights [chunk][N/32][4][64][4] (see fold.py: pack_igemm)
+    int H, W, C;
+    int KH, KW, sh, sw, pt, pl;
+    int nchunks;        // KH*KW*C/32
+};
+
+struct ConvArgs {
+    ConvSeg seg[2];
+    int nseg;
+    int Ho, Wo;
+    int M;              // B*Ho*Wo
+    int N;              // padded output channels (multiple of the N tile)
+    int Nreal;          // stored channels
+    int ldo;            // out row stride
+    float* out;
+    // epilogue: v = acc + cb[clip(b)*cb_stride + n] + ts[ho*N+n] + fs[wo*N+n]
+    //           aux[m*aux_ld+n] = v (optional)
+    //           v += idw[n]*id[m*id_ld+n]                       (id_mode 1: same-shape tensor)
+    //           v += idw[n]*ids[(b*idH + ho*idsh)*idW + wo*idsw] (id_mode 2: 1-channel image)
+    //           out = relu ? max(v,0) : v
+    const float* cb;
+    int cb_stride;
+    const int* img_clip;   // nullable -> clip 0
+    const float* ts;       // nullable
+    const float* fs;       // nullable
+    int id_mode;
+    const float* id;
+    int id_ld;
+    const float* idw;
+    int idH, idW, idsh, idsw;
+    int relu;
+    float* aux;
+    int aux_ld;
+    FastDiv fdHoWo, fdWo;
+};
+
+// returns algorithmic FLOPs of the launch (2*M*K*Nreal)
+double launch_conv_igemm(const ConvArgs& a, hipStream_t s);
+
+// ---------------------------------------------------------------------------------------------
+// Small kernels (aux_kernels.hip)
+struct DirectArgs {     // convolution of a 1-channel image into 64 channels, same epilogue terms
+    const float* src;   // [B, H, W]
+    const float* w;     // [KH*KW][64], BN scale folded in
+    int H, W, KH, KW, sh, sw, pt, pl, Ho, Wo;
+    int M;              // B*Ho*Wo
+    float* out;         // [M, 64]
+    const float* cb;
+    int cb_stride;
+    const int* img_clip;
+    const float* ts;    // [Ho,64] nullable
+    const float* fs;    // [Wo,64] nullable
+    int relu;
+    FastDiv fdHoWo, fdWo;
+};
+void launch_direct_conv64(const DirectArgs& a, hipStream_t s);
+
+// frame index: for global frame g -> clip, t within clip, T of clip
+void launch_frame_index(const int64_t* frame_offsets_dev, int nclips, int64_t total, int* f_clip,
+                        int* f_t, int* f_T, hipStream_t s);
+// xw[i, h, w] = logmag row (g0+i) - t + (t+h-17) or 0.0 outside the clip   (SN/apply.py:170-186)
+void launch_gather_windows(const float* logmag, const int* f_t, const int* f_T, int64_t g0, int n,
+                           float* xw, hipStream_t s);
+// mean over HW positions: x [B, HW, C] -> out [B, C]
+void launch_avgpool(const float* x, int B, int HW, int C, float* out, hipStream_t s);
+// cb[clip, n] = base[n] + sum_k ea[clip,k]*Wc[k, n] + sum_k eb[clip,k]*Wc[512+k, n]
+void launch_cond(const float* ea, const float* eb, int nclips, const float* Wc, const float* base,
+                 int ncols, float* cb, hipStream_t s);
+
+// ---------------------------------------------------------------------------------------------
+// STFT / iSTFT (stft.hip)
+struct ClipTable {      // device arrays, one entry per clip
+    const int64_t* sample_off;   // [nclips+1] offsets into the wav buffer
+    const int64_t* frame_off;    // [nclips+1] offsets into [T_total,201] tensors
+    const int64_t* out_off;      // [nclips+1] (iSTFT) offsets into the output wav buffer
+};
+// grid = one block per (clip, run of kStftFramesPerBlock frames); block_clip/block_f0 enumerate them
+void launch_stft(const float* wav, ClipTable t, const int* block_clip, const int* block_f0, int nblocks,
+                 const float* tw400 /*400 cplx*/, const float* window /*400*/, float* logmag,
+                 float* phase, hipStream_t s);
+void launch_istft(const float* logmag, const float* phase, ClipTable t, const int* block_clip,
+                  const int* block_h0, int nblocks, const float* tw400, const float* wsyn /*400*/,
+                  float* wav_out, hipStream_t s);
+constexpr int kStftFramesPerBlock = 24;   // 4 waves x 3 frames x 2 passes
+constexpr int kIstftHopsPerBlock = 22;    // output hops per block; needs 24 frames
+
+}  // namespace nhans

@@ -1,0 +1,218 @@
+// STFT feature extraction and inverse STFT / overlap-add for N-HANS (16 kHz, 400-sample periodic
+// Hann window, hop 160, 201 bins).
+//
+//   stft_features_kernel : tf.signal.stft(wav, 400, 160, fft_length=400) -> log(|X| + 1e-5), angle(X)
+//                          (SN/apply.py:368-375, SN/reader.py:334-350)
+//   istft_ola_kernel     : exp(logmag) * e^{j phase} -> tf.signal.inverse_stft(400, 160, 400,
+//                          window_fn=inverse_stft_window_fn(160, hann periodic))   (SN/apply.py:189-204)
+//
+// Both are HBM-bound (2,248 algorithmic bytes per frame).  A workgroup of 4 wavefronts handles a
+// run of consecutive frames of one clip: the sample span (400 + 160*(F-1) samples) is loaded once,
+// coalesced, into LDS, so each input sample crosses HBM once although it belongs to 2.5 frames.
+// The 400-point transform is 20 x 20 (fft400.h): every lane computes one 20-point DFT in
+// registers, a wavefront carries 3 frames (60 of 64 lanes busy), and the 20x20 transpose between
+// the two passes goes through LDS rows padded to 21 complex values.  log/atan2 (and exp/sincos
+// on the way back) are spread over all 64 lanes and written as contiguous 201-float rows.
+// Overlap-add is in gather form: each output sample is summed by one thread from its <= 3
+// windowed frames in ascending frame order -- no atomics, bitwise deterministic.
+#include "nhans_kernels.h"
+#include "fft400.h"
+
+namespace nhans {
+
+constexpr int kFpw = 3;                 // frames per wavefront per pass
+constexpr int kTRow = 21;               // padded transpose row (complex values)
+constexpr int kTFrame = 20 * kTRow;     // 420 complex per frame
+
+__global__ void __launch_bounds__(256) stft_features_kernel(
+    const float* __restrict__ wav, ClipTable tab, const int* __restrict__ block_clip,
+    const int* __restrict__ block_f0, const cplx* __restrict__ tw400g, const float* __restrict__ windowg,
+    float* __restrict__ logmag, float* __restrict__ phase) {
+    constexpr int F = kStftFramesPerBlock;
+    constexpr int SPAN = kWin + kHop * (F - 1);
+    __shared__ __attribute__((aligned(16))) float xs[SPAN];
+    __shared__ float win[kWin];
+    __shared__ cplx tw[400];
+    __shared__ cplx tbuf[4 * kFpw * kTFrame];      // transpose buffer; spectrum rows alias it per wave
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int clip = block_clip[blockIdx.x], f0 = block_f0[blockIdx.x];
+    const int64_t s_beg = tab.sample_off[clip], s_end = tab.sample_off[clip + 1];
+    const int64_t fr_beg = tab.frame_off[clip];
+    const int T = (int)(tab.frame_off[clip + 1] - fr_beg);
+
+    for (int i = tid; i < 400; i += 256) { tw[i] = tw400g[i]; win[i] = windowg[i]; }
+    {
+        const int64_t base = s_beg + (int64_t)f0 * kHop;
+        for (int i = tid; i < SPAN; i += 256) xs[i] = (base + i < s_end) ? wav[base + i] : 0.f;
+    }
+    __syncthreads();
+
+    const int j = lane / 20, q = lane - j * 20;     // frame slot within the wave, DFT column/row
+    const bool active = lane < 60;
+    cplx* tw_wave = tbuf + wave * kFpw * kTFrame;
+
+#pragma unroll 1
+    for (int p = 0; p < F / (4 * kFpw); ++p) {
+        const int lf0 = p * 4 * kFpw + wave * kFpw;  // first local frame of this wave
+        if (active) {
+            // pass 1: lane = n2; 20-point DFT over n1 of the windowed samples x[20*n1 + n2]
+            cplx col[20], y[20];
+            const float* xf = xs + (lf0 + j) * kHop;
+#pragma unroll
+            for (int n1 = 0; n1 < 20; ++n1) col[n1] = cmake(xf[20 * n1 + q] * win[20 * n1 + q], 0.f);
+            fft400_pass1<false>(col, q, tw, y);
+            cplx* tf = tw_wave + j * kTFrame;
+#pragma unroll
+            for (int k1 = 0; k1 < 20; ++k1) tf[k1 * kTRow + q] = y[k1];
+        }
+        __syncthreads();
+        cplx X[20];
+        if (active) {
+            // pass 2: lane = k1; 20-point DFT over n2 -> X[k1 + 20*k2]
+            cplx row[20];
+            const cplx* tf = tw_wave + j * kTFrame + q * kTRow;
+#pragma unroll
+            for (int n2 = 0; n2 < 20; ++n2) row[n2] = tf[n2];
+            fft400_pass2<false>(row, X);
+        }
+        __syncthreads();
+        if (active) {
+            // bins 0..200 only: k = q + 20*k2 with k2 <= 9, plus k = 200 (q = 0, k2 = 10)
+            cplx* sp = tw_wave + j * kBins;          // [3][201] spectrum rows, aliasing the transpose
+#pragma unroll
+            for (int k2 = 0; k2 < 10; ++k2) sp[q + 20 * k2] = X[k2];
+            if (q == 0) sp[200] = X[10];
+        }
+        __syncthreads();
+        {
+            const int fglob0 = f0 + lf0;             // first frame of this wave (clip-relative)
+            for (int idx = lane; idx < kFpw * kBins; idx += 64) {
+                const int jj = idx / kBins;
+                if (fglob0 + jj >= T) break;
+                const cplx v = tw_wave[idx];
+                const float mag = sqrtf(v.x * v.x + v.y * v.y);
+                const int64_t o = (fr_beg + fglob0) * kBins + idx;
+                logmag[o] = logf(mag + 1e-5f);
+                if (phase) phase[o] = atan2f(v.y, v.x);
+            }
+        }
+        __syncthreads();
+    }
+}
+
+void launch_stft(const float* wav, ClipTable t, const int* block_clip, const int* block_f0, int nblocks,
+                 const float* tw400, const float* window, float* logmag, float* phase, hipStream_t s) {
+    if (nblocks <= 0) return;
+    hipLaunchKernelGGL(stft_features_kernel, dim3(nblocks), dim3(256), 0, s, wav, t, block_clip, block_f0,
+                       reinterpret_cast<const cplx*>(tw400), window, logmag, phase);
+}
+
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) istft_ola_kernel(
+    const float* __restrict__ logmag, const float* __restrict__ phase, ClipTable tab,
+    const int* __restrict__ block_clip, const int* __restrict__ block_h0, const cplx* __restrict__ tw400g,
+    const float* __restrict__ wsyng, float* __restrict__ wav_out) {
+    constexpr int HB = kIstftHopsPerBlock;          // output hops per block
+    constexpr int F = HB + 2;                        // frames needed: h0-2 .. h0+HB-1
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    cplx* tw = reinterpret_cast<cplx*>(smem_raw);                 // 400
+    cplx* tbuf = tw + 400;                                        // 4*3*420
+    cplx* sbuf = tbuf + 4 * kFpw * kTFrame;                       // 4*3*201
+    float* wsyn = reinterpret_cast<float*>(sbuf + 4 * kFpw * kBins);   // 400
+    float* y = wsyn + kWin;                                       // F*400
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int clip = block_clip[blockIdx.x], h0 = block_h0[blockIdx.x];
+    const int64_t fr_beg = tab.frame_off[clip];
+    const int T = (int)(tab.frame_off[clip + 1] - fr_beg);
+    const int64_t nout = (int64_t)(T - 1) * kHop + kWin;
+
+    for (int i = tid; i < 400; i += 256) { tw[i] = tw400g[i]; wsyn[i] = wsyng[i]; }
+    __syncthreads();
+
+    const int j = lane / 20, q = lane - j * 20;
+    const bool active = lane < 60;
+    cplx* t_wave = tbuf + wave * kFpw * kTFrame;
+    cplx* s_wave = sbuf + wave * kFpw * kBins;
+
+#pragma unroll 1
+    for (int p = 0; p < F / (4 * kFpw); ++p) {
+        const int lf0 = p * 4 * kFpw + wave * kFpw;          // local frame index; clip frame = h0-2+lf
+        // spectrum: |S| = exp(logmag), S = |S| e^{j phase}; frames outside [0,T) contribute zero
+        for (int idx = lane; idx < kFpw * kBins; idx += 64) {
+            const int jj = idx / kBins;
+            const int fr = h0 - 2 + lf0 + jj;
+            cplx v = cmake(0.f, 0.f);
+            if (fr >= 0 && fr < T) {
+                const int64_t o = (fr_beg + fr) * kBins + (idx - jj * kBins);
+                const float mag = expf(logmag[o]);
+                float sn, cs;
+                sincosf(phase[o], &sn, &cs);
+                v = cmake(mag * cs, mag * sn);
+            }
+            s_wave[idx] = v;
+        }
+        __syncthreads();
+        if (active) {
+            // pass 1 over the Hermitian-extended spectrum: lane = b, inputs X[20a + b]
+            cplx col[20], yv[20];
+            const cplx* sp = s_wave + j * kBins;
+#pragma unroll
+            for (int a = 0; a < 20; ++a) {
+                const int k = 20 * a + q;
+                col[a] = (k <= 200) ? sp[k] : cconj(sp[400 - k]);
+            }
+            fft400_pass1<true>(col, q, tw, yv);
+            cplx* tf = t_wave + j * kTFrame;
+#pragma unroll
+            for (int c1 = 0; c1 < 20; ++c1) tf[c1 * kTRow + q] = yv[c1];
+        }
+        __syncthreads();
+        if (active) {
+            cplx row[20], x[20];
+            const cplx* tf = t_wave + j * kTFrame + q * kTRow;
+#pragma unroll
+            for (int b = 0; b < 20; ++b) row[b] = tf[b];
+            fft400_pass2<true>(row, x);
+            float* yf = y + (lf0 + j) * kWin;
+#pragma unroll
+            for (int c2 = 0; c2 < 20; ++c2) {
+                const int n = q + 20 * c2;
+                yf[n] = x[c2].x * (1.0f / 400.0f) * wsyn[n];     // real part of the inverse transform
+            }
+        }
+        __syncthreads();
+    }
+
+    // gather-form overlap-add: sample i of hop u sums frames u-2, u-1, u (ascending)
+    const int64_t obase = tab.out_off[clip];
+    for (int i = tid; i < HB * kHop; i += 256) {
+        const int hl = i / kHop, r = i - hl * kHop;
+        const int64_t pos = (int64_t)(h0 + hl) * kHop + r;
+        if (pos >= nout) break;
+        float acc = 0.f;
+        if (r < kWin - 2 * kHop) acc = y[hl * kWin + 2 * kHop + r];
+        acc += y[(hl + 1) * kWin + kHop + r];
+        acc += y[(hl + 2) * kWin + r];
+        wav_out[obase + pos] = acc;
+    }
+}
+
+void launch_istft(const float* logmag, const float* phase, ClipTable t, const int* block_clip,
+                  const int* block_h0, int nblocks, const float* tw400, const float* wsyn, float* wav_out,
+                  hipStream_t s) {
+    if (nblocks <= 0) return;
+    constexpr size_t lds = (400 + 4 * kFpw * kTFrame + 4 * kFpw * kBins) * sizeof(cplx) +
+                           (kWin + (kIstftHopsPerBlock + 2) * kWin) * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&istft_ola_kernel),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(istft_ola_kernel, dim3(nblocks), dim3(256), lds, s, logmag, phase, t, block_clip,
+                       block_h0, reinterpret_cast<const cplx*>(tw400), wsyn, wav_out);
+}
+
+}  // namespace nhans

@@ -1,0 +1,161 @@
+"""Host-side constant folding of an N-HANS checkpoint into the blob libnhans_hip.so consumes.
+
+Everything that depends only on the weights is evaluated once here, in float64, and rounded to
+float32 at the end:
+  * inference BatchNorm (SN/blocks.py:104-108) -> per-channel scale/shift; the scale is multiplied
+    into the convolution / projection weights and the position tables, the shift into the bias;
+  * the time/frequency position MLPs `cont_embed` (SN/main.py:127-137) -> tables t[Ho,C], f[Wo,C];
+  * conv bias, `_transform` bias and the two projection biases -> one additive row per conv;
+  * the 16 conditioning projections (SN/main.py:139-148) -> one [1024, 3840] matrix;
+  * HWIO kernels -> the MFMA fragment order of conv_igemm.hip (`pack_igemm`).
+
+Blob layout (little endian): header {char magic[8]="NHANSFW1"; u32 version=1; u32 n_entries;
+u64 total_bytes}, then n_entries x {char name[48]; u64 offset; u64 nfloats}, then float32 arrays
+at 256-byte-aligned offsets.
+"""
+import struct
+
+import numpy as np
+
+from . import spec
+
+F64 = np.float64
+
+
+def _bn(W, scope):
+    g = W[scope + "/gamma"].astype(F64).reshape(-1)
+    b = W[scope + "/beta"].astype(F64).reshape(-1)
+    m = W[scope + "/pop_mean"].astype(F64).reshape(-1)
+    v = W[scope + "/pop_variance"].astype(F64).reshape(-1)
+    scale = g / np.sqrt(v + spec.BN_EPS)
+    return scale, b - m * scale
+
+
+def _cont_embed(W, n, scope):
+    """Position table of `n` rows (SN/main.py:127-137); BN scopes are doubled (`scope+scope`)."""
+    z = np.arange(n, dtype=F64).reshape(n, 1)
+    for i in (1, 2):
+        s, sh = _bn(W, "%s%s_dense%d" % (scope, scope, i))
+        z = np.maximum((z @ W["%s_dense%d/w" % (scope, i)].astype(F64)) * s + sh, 0.0)
+    return z @ W[scope + "_dense3/w"].astype(F64)
+
+
+def pack_igemm(wkn, npad=None):
+    """[K, N] (K = kh*kw*cin in HWIO order, multiple of 32) -> float32 [K/32][Npad/32][4][64][4]
+    so that lane l of MFMA (q, e) of chunk c, n-tile t reads W[32c + 8q + 4(l>>5) + e][32t + (l&31)]
+    as element e of one 16-byte vector (conv_igemm.hip)."""
+    k, n = wkn.shape
+    assert k % 32 == 0, k
+    npad = n if npad is None else npad
+    assert npad % 32 == 0 and npad >= n
+    wp = np.zeros((k, npad), dtype=F64)
+    wp[:, :n] = wkn
+    a = wp.reshape(k // 32, 4, 2, 4, npad // 32, 32)       # chunk, q, half, e, nt, col
+    a = a.transpose(0, 4, 1, 2, 5, 3)                       # chunk, nt, q, half, col, e
+    return np.ascontiguousarray(a).reshape(-1).astype(np.float32)
+
+
+def fold_arrays(W, kind):
+    """-> dict name -> float32 1-D array (see nhans_api.hip for the consumer)."""
+    out = {}
+    w64 = lambda n: W[n].astype(F64)
+
+    # --- transform constants (tf.signal.stft / inverse_stft_window_fn)
+    j = np.arange(spec.WIN, dtype=F64)
+    ang = -2.0 * np.pi * j / spec.WIN
+    out["tw400"] = np.stack([np.cos(ang), np.sin(ang)], 1).reshape(-1)
+    win = 0.5 - 0.5 * np.cos(2.0 * np.pi * j / spec.WIN)
+    out["window"] = win
+    den = np.zeros(spec.HOP, dtype=F64)
+    for q in range(-(-spec.WIN // spec.HOP)):
+        seg = win[q * spec.HOP:(q + 1) * spec.HOP] ** 2
+        den[:len(seg)] += seg
+    out["wsyn"] = win / np.tile(den, -(-spec.WIN // spec.HOP))[:spec.WIN]
+
+    # --- embedding tower (SN/main.py:102-124,190-216)
+    for i, g in enumerate(spec.tower_geometry()):
+        p, s = "t%d" % i, "embedding/" + g["name"]
+        s1, h1 = _bn(W, s + "_conv1")
+        w1 = w64(s + "_conv1/w").reshape(-1, g["cout"]) * s1
+        if g["cin"] == 1:
+            out[p + ".c1.w"] = w1.reshape(-1)
+        else:
+            out[p + ".c1.wpk"] = pack_igemm(w1)
+        out[p + ".c1.cb"] = h1
+        sa, ha = _bn(W, s + "_addition")
+        out[p + ".c2.wpk"] = pack_igemm(w64(s + "_conv2/w").reshape(-1, g["cout"]) * sa)
+        wt = w64(s + "_transform/w").reshape(g["cin"], g["cout"]) * sa
+        if g["cin"] == 1:
+            out[p + ".c2.idw"] = wt.reshape(-1)
+        else:
+            out[p + ".c2.wpk_t"] = pack_igemm(wt)
+        out[p + ".c2.cb"] = sa * (w64(s + "_conv2/b").reshape(-1) + w64(s + "_transform/b").reshape(-1)) + ha
+
+    # --- conditioned stack (SN/main.py:126-187,219-229)
+    ea, eb = spec.emb_scopes(kind)
+    cond_w, cond_b = [], []
+    for i, g in enumerate(spec.main_geometry()):
+        p, s, c = "m%d" % i, g["name"], g["cout"]
+        s1, h1 = _bn(W, s + "_conv1")
+        sa, ha = _bn(W, s + "_addition")
+        w1 = w64(s + "_conv1/w").reshape(-1, c) * s1
+        if g["cin"] == 1:
+            out[p + ".c1.w"] = w1.reshape(-1)
+        else:
+            out[p + ".c1.wpk"] = pack_igemm(w1)
+        out[p + ".c2.wpk"] = pack_igemm(w64(s + "_conv2/w").reshape(-1, c) * sa)
+        extra_bias = w64(s + "_conv2/b").reshape(-1)
+        if g["cin"] == 1:
+            out[p + ".c2.idw"] = w64(s + "_transform/w").reshape(-1) * sa
+            extra_bias = extra_bias + w64(s + "_transform/b").reshape(-1)
+        elif g["cin"] != c:
+            out[p + ".c2.wpk_t"] = pack_igemm(w64(s + "_transform/w").reshape(g["cin"], c) * sa)
+            out[p + ".c2.idw"] = np.zeros(c)          # unused: the transform rides in the K loop
+            extra_bias = extra_bias + w64(s + "_transform/b").reshape(-1)
+        else:
+            out[p + ".c2.idw"] = sa
+        for cv, sc, sh, bias in ((1, s1, h1, 0.0), (2, sa, ha, extra_bias)):
+            q = "%s_conv%d" % (s, cv)
+            out["%s.c%d.ts" % (p, cv)] = (_cont_embed(W, g["hout"], q + "_temb") * sc).reshape(-1)
+            out["%s.c%d.fs" % (p, cv)] = (_cont_embed(W, g["wout"], q + "_femb") * sc).reshape(-1)
+            cond_w.append(np.concatenate([w64(q + ea + "/w"), w64(q + eb + "/w")], 0) * sc)
+            cond_b.append(sc * (w64(q + ea + "/b").reshape(-1) + w64(q + eb + "/b").reshape(-1) + bias) + sh)
+    out["cond.w"] = np.concatenate(cond_w, 1).reshape(-1)       # [1024, 3840]
+    out["cond.base"] = np.concatenate(cond_b, 0)
+
+    # --- head (SN/main.py:232-242)
+    s, h = _bn(W, "last_conv")
+    out["head.conv.wpk"] = pack_igemm(w64("last_conv/w").reshape(-1, 512) * s)
+    out["head.conv.cb"] = h
+    out["head.dense.wpk"] = pack_igemm(w64("last_dense/w"), 256)
+    cb = np.zeros(256)
+    cb[:spec.BINS] = w64("last_dense/b").reshape(-1)
+    out["head.dense.cb"] = cb
+    out["head.dense.idw"] = np.ones(256)
+    return {k: np.ascontiguousarray(v, dtype=np.float32).reshape(-1) for k, v in out.items()}
+
+
+def write_blob(arrays):
+    names = sorted(arrays)
+    head = 24 + 64 * len(names)
+    off = (head + 255) & ~255
+    entries, chunks = [], []
+    for n in names:
+        a = arrays[n]
+        nb = n.encode("ascii")
+        assert len(nb) < 48, n
+        entries.append(struct.pack("<48sQQ", nb, off, a.size))
+        chunks.append((off, a))
+        off = (off + a.nbytes + 255) & ~255
+    blob = bytearray(off)
+    blob[0:24] = struct.pack("<8sIIQ", b"NHANSFW1", 1, len(names), off)
+    for i, e in enumerate(entries):
+        blob[24 + 64 * i:24 + 64 * (i + 1)] = e
+    for o, a in chunks:
+        blob[o:o + a.nbytes] = a.tobytes()
+    return bytes(blob)
+
+
+def fold_weights(W, kind):
+    """Checkpoint dict -> blob bytes for nhans_create()."""
+    return write_blob(fold_arrays(W, kind))

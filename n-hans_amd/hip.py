@@ -1,0 +1,93 @@
+"""ctypes binding of libnhans_hip.so (C ABI in include/nhans_hip.h).
+
+There is no CPU fallback: if the shared library is missing or fails to load, every use raises.
+"""
+import ctypes
+import json
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libnhans_hip.so")
+
+DENOISER, SEPARATOR = 0, 1
+KIND_CODE = {"denoiser": DENOISER, "separator": SEPARATOR}
+
+EXPORTS = [
+    "nhans_abi_version", "nhans_last_error", "nhans_num_frames", "nhans_create", "nhans_destroy",
+    "nhans_set_option", "nhans_workspace_bytes", "nhans_stft_features", "nhans_embed",
+    "nhans_mask_net", "nhans_istft", "nhans_enhance_clips", "nhans_debug_block_output",
+    "nhans_profile_json", "nhans_profile_reset",
+]
+
+_lib = None
+
+
+class NhansError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the HIP library once; raises NhansError if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise NhansError("%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                         "or `make -C n-hans_amd/csrc` (there is no CPU fallback)" % LIB_PATH)
+    import torch  # noqa: F401  -- makes torch's libamdhip64.so.7 the process-wide HIP runtime first
+    lib = ctypes.CDLL(LIB_PATH)
+    vp, i64p = ctypes.c_void_p, ctypes.POINTER(ctypes.c_int64)
+    lib.nhans_abi_version.restype = ctypes.c_int
+    lib.nhans_last_error.restype = ctypes.c_char_p
+    lib.nhans_num_frames.restype = ctypes.c_int64
+    lib.nhans_num_frames.argtypes = [ctypes.c_int64]
+    lib.nhans_create.argtypes = [ctypes.c_int, vp, ctypes.c_size_t, ctypes.c_int, ctypes.POINTER(vp)]
+    lib.nhans_destroy.argtypes = [vp]
+    lib.nhans_destroy.restype = None
+    lib.nhans_set_option.argtypes = [vp, ctypes.c_char_p, ctypes.c_int64]
+    lib.nhans_workspace_bytes.argtypes = [vp, ctypes.c_int64, ctypes.c_int]
+    lib.nhans_workspace_bytes.restype = ctypes.c_size_t
+    lib.nhans_stft_features.argtypes = [vp, vp, i64p, ctypes.c_int, ctypes.c_int, vp, vp, vp]
+    lib.nhans_embed.argtypes = [vp, vp, ctypes.c_int, vp, vp]
+    lib.nhans_mask_net.argtypes = [vp, vp, i64p, ctypes.c_int, vp, vp, vp, vp, vp]
+    lib.nhans_istft.argtypes = [vp, vp, vp, i64p, ctypes.c_int, i64p, vp, vp]
+    lib.nhans_enhance_clips.argtypes = [vp, vp, i64p, ctypes.c_int, vp, i64p, vp, i64p, vp, vp, vp, vp, vp, vp, vp]
+    lib.nhans_debug_block_output.argtypes = [vp, vp, i64p, ctypes.c_int, vp, vp, ctypes.c_int64, ctypes.c_int,
+                                             ctypes.c_int, vp, vp]
+    lib.nhans_profile_json.argtypes = [vp, ctypes.c_char_p, ctypes.c_size_t]
+    lib.nhans_profile_reset.argtypes = [vp]
+    for name in ("nhans_create", "nhans_set_option", "nhans_stft_features", "nhans_embed", "nhans_mask_net",
+                 "nhans_istft", "nhans_enhance_clips", "nhans_debug_block_output", "nhans_profile_json",
+                 "nhans_profile_reset"):
+        getattr(lib, name).restype = ctypes.c_int
+    if lib.nhans_abi_version() != 1:
+        raise NhansError("libnhans_hip.so ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def check(rc):
+    if rc < 0:
+        raise NhansError("libnhans_hip: %s (code %d)" % (load().nhans_last_error().decode(), rc))
+    return rc
+
+
+def i64_array(values):
+    arr = (ctypes.c_int64 * len(values))(*[int(v) for v in values])
+    return arr
+
+
+def ptr(t):
+    """Device pointer of a contiguous torch tensor (None -> NULL)."""
+    if t is None:
+        return None
+    assert t.is_contiguous()
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def profile_dict(handle):
+    lib = load()
+    n = lib.nhans_profile_json(handle, None, 0)
+    buf = ctypes.create_string_buffer(n + 1)
+    lib.nhans_profile_json(handle, buf, n + 1)
+    return json.loads(buf.value.decode())

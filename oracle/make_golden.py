@@ -1,0 +1,117 @@
+"""Generates the committed golden vectors under tests/golden/ from the float64 oracle.
+
+Run in the build container (needs /root/reference only for the shipped example wavs and .index
+files, which are data):   python oracle/make_golden.py
+The GPU box never runs this; it reads the .npz/.json/.wav fixtures.
+
+Weights are the seeded synthetic recipe (nhans_amd.weights.synthetic_weights, seed 7) because the
+reference's trained weights are git-LFS pointers; inputs are the reference's exp2_noisy.wav and
+seeded synthetic material (nhans_amd.synth).
+"""
+import json
+import os
+import shutil
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import nhans_amd  # noqa: E402,F401
+from nhans_amd import spec, synth, tfbundle, weights  # noqa: E402
+from oracle import nhans_oracle as O  # noqa: E402
+
+REF = "/root/reference"
+SN = REF + "/N_HANS___Selective_Noise"
+SS = REF + "/N_HANS___Source_Separation"
+OUT = os.path.join(ROOT, "tests", "golden")
+SUB = 97          # block activations are stored subsampled: flat[::SUB]
+
+
+def f32(a):
+    return np.asarray(a, dtype=np.float32)
+
+
+def run_case(W, kind, mix, ca, cb, frames, tap_frames):
+    """Oracle stages on normalised inputs; network only on `frames` (None = all)."""
+    t0 = time.time()
+    res = O.enhance(mix, ca, cb, W, kind, batch=8, frames=frames)
+    out = dict(logmag=f32(res["logmag"]), phase=f32(res["phase"]), emb_a=f32(res["emb_a"]), emb_b=f32(res["emb_b"]))
+    sel = np.arange(res["logmag"].shape[0]) if frames is None else np.asarray(frames)
+    out["frames"] = sel.astype(np.int32)
+    out["logits"] = f32(res["logits"][sel])
+    if frames is None:
+        out["denoised_wav"] = f32(res["denoised_wav"])
+        out["mixed_wav"] = f32(res["mixed_wav"])
+    if tap_frames:
+        win = O.strided_crop(res["logmag"], O.MIX_WIN)
+        taps = {}
+        n = len(tap_frames)
+        O.mask_net(win[tap_frames], np.repeat(res["emb_a"][None], n, 0), np.repeat(res["emb_b"][None], n, 0), W, kind, taps)
+        out["tap_frames"] = np.asarray(tap_frames, dtype=np.int32)
+        for i, (name, _) in enumerate(O.STACK):
+            out["block%d" % i] = f32(taps[name].reshape(-1)[::SUB])
+        out["block8"] = f32(taps["last_conv"].reshape(-1)[::SUB])
+    print("  case done in %.1f s" % (time.time() - t0), flush=True)
+    return out
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    # ---- data fixtures from the reference tree
+    shutil.copyfile(SN + "/audio_examples/exp2_noisy.wav", OUT + "/exp2_noisy.wav")
+    os.chmod(OUT + "/exp2_noisy.wav", 0o644)
+    geo = {"cases": [], "examples": {}}
+    for n in (49600, 63520, 160000, 400, 559, 560, 399, 32240):
+        kept, t = spec.frames_for_samples(n)
+        geo["cases"].append({"n": n, "kept": kept, "frames": t, "out_len": (t - 1) * 160 + 400 if t else 0})
+    from scipy.io import wavfile
+    for name in ("exp1", "exp2"):
+        _, a = wavfile.read("%s/audio_examples/%s_noisy.wav" % (SN, name))
+        r, b = wavfile.read("%s/audio_examples/%s_denoised.wav" % (SN, name))
+        geo["examples"][name] = {"in_len": int(len(a)), "out_len": int(len(b)), "out_dtype": str(b.dtype), "rate": int(r)}
+    ws = O.istft_window()
+    geo["wsyn"] = {"0": float(ws[0]), "1": float(ws[1]), "200": float(ws[200]), "399": float(ws[399])}
+    json.dump(geo, open(OUT + "/geometry.json", "w"), indent=1)
+    inv = {}
+    for kind, prefix in (("denoiser", SN + "/trained_model/81448_0-1000000"), ("separator", SS + "/trained_model/81457_2-545000")):
+        ent = tfbundle.read_index(prefix + ".index")
+        inv[kind] = [[k, list(v["shape"]), v["dtype"], v["offset"], v["size"]] for k, v in ent.items()]
+    json.dump(inv, open(OUT + "/checkpoint_index.json", "w"))
+
+    Wd = weights.synthetic_weights("denoiser", 7)
+    Ws = weights.synthetic_weights("separator", 7)
+
+    print("case exp2 (denoiser, all 308 frames)", flush=True)
+    mix = O.trim_to_frames(O.normalise(O.read_wav(OUT + "/exp2_noisy.wav")))
+    res = run_case(Wd, "denoiser", mix, O.normalise(synth.silent()), O.normalise(synth.noise_context(0)), None, [0, 154])
+    np.savez_compressed(OUT + "/case_exp2.npz", **res)
+
+    print("case synth10s (denoiser, 10 s clip, 12 frames)", flush=True)
+    mix = O.trim_to_frames(O.normalise(synth.mixture(0, 10.0)))
+    fr = [0, 1, 16, 17, 18, 250, 499, 700, 979, 980, 996, 997]
+    res = run_case(Wd, "denoiser", mix, O.normalise(synth.silent()), O.normalise(synth.noise_context(0)), fr, None)
+    np.savez_compressed(OUT + "/case_synth10s.npz", **res)
+
+    print("case separator (2 s, 8 frames)", flush=True)
+    mix = O.trim_to_frames(O.normalise(synth.mixture(3, 2.0)))
+    res = run_case(Ws, "separator", mix, O.normalise(synth.speaker_context(3, low=False)),
+                   O.normalise(synth.speaker_context(3, low=True)), [0, 5, 40, 99, 100, 150, 196, 197], [99])
+    np.savez_compressed(OUT + "/case_separator.npz", **res)
+
+    print("case ragged (3 short clips, all frames)", flush=True)
+    lens = [400, 560, 16000 + 80]          # 1, 2 and 98 frames (the last one gets trimmed by 80)
+    allres = {}
+    for i, n in enumerate(lens):
+        mix = O.trim_to_frames(O.normalise(synth.mixture(10 + i, n / 16000.0)))
+        r = run_case(Wd, "denoiser", mix, O.normalise(synth.silent()), O.normalise(synth.noise_context(10 + i)), None, None)
+        for k in ("logmag", "logits", "denoised_wav", "emb_b"):
+            allres["%s_%d" % (k, i)] = r[k]
+    allres["lens"] = np.asarray(lens, dtype=np.int64)
+    np.savez_compressed(OUT + "/case_ragged.npz", **allres)
+    print("golden vectors written to", OUT)
+
+
+if __name__ == "__main__":
+    main()
