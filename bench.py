@@ -1,0 +1,177 @@
+#!/usr/bin/env python3
+"""Throughput of the N-HANS hot path (STFT -> embedding towers -> conditioned residual mask net ->
+iSTFT) on MI355X.  One step = one pass over one batch of synthetic 10 s / 16 kHz mixtures per GPU,
+inputs already resident in HBM, including (N > 1) the single RCCL all-gather of the outputs.
+
+    python bench.py --gpus 1 --steps 5 --warmup 2
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Prints ONE JSON line on rank 0 (contract in the task statement).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+import nhans_amd  # noqa: E402,F401
+from nhans_amd import engine, spec, synth, weights  # noqa: E402
+from nhans_amd.apply import normalise, trim_to_frames  # noqa: E402
+
+F32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+HBM_PEAK_GBS = 8000.0
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=5)
+    p.add_argument("--warmup", type=int, default=2)
+    p.add_argument("--clips-per-gpu", type=int, default=1,
+                   help="1 = BASELINE configs[1] (single 10 s clip); 256 = configs[2]")
+    p.add_argument("--seconds", type=float, default=10.0)
+    p.add_argument("--kind", default="denoiser", choices=["denoiser", "separator"])
+    p.add_argument("--frames-per-chunk", type=int, default=0)
+    p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--cpu-frames", type=int, default=32, help="frames of the CPU baseline sample")
+    p.add_argument("--cpu-threads", type=int, default=0, help="0 = min(host cores, 64)")
+    return p.parse_args()
+
+
+def make_batch(kind, rank, clips, seconds):
+    """Synthetic clips for this rank, through the reference's normalise/trim (apply.py)."""
+    mixes, ca, cb = [], [], []
+    # only a few distinct clips are synthesised; they are tiled to the requested batch size
+    distinct = min(clips, 4)
+    for i in range(distinct):
+        cid = rank * clips + i
+        mixes.append(trim_to_frames(normalise(synth.mixture(cid, seconds))))
+        if kind == "denoiser":
+            ca.append(normalise(synth.silent()))                 # --pos default: Silent.wav
+            cb.append(normalise(synth.noise_context(cid)))       # --neg
+        else:
+            ca.append(normalise(synth.speaker_context(cid, low=True)))    # interferer (--neg)
+            cb.append(normalise(synth.speaker_context(cid, low=False)))   # target (--pos)
+    rep = lambda lst: [lst[i % distinct] for i in range(clips)]
+    return rep(mixes), rep(ca), rep(cb)
+
+
+def cpu_baseline(W, kind, mix, ca, cb, frames, hip_wav, threads):
+    """Reference-faithful float32 CPU path (oracle/torch_ref.py) on a bounded sample."""
+    from oracle.torch_ref import TorchRef
+    torch.set_num_threads(threads or min(os.cpu_count() or 1, 64))
+    ref = TorchRef(W, kind, torch.float32)
+    t0 = time.time()
+    out = ref.enhance(mix, ca, cb, faithful=True, mb=frames, max_batches=1)
+    dt = time.time() - t0
+    n = out["frames_done"]
+    res = {"value": (n / dt) / 100.0, "unit": "audio-seconds/s", "cores": torch.get_num_threads(), "kind": "port",
+           "frames_per_s": n / dt,
+           "sample": "first %d-frame minibatch of clip 0, float32 torch-CPU restatement in reference-faithful mode "
+                     "(both 200-frame contexts tiled per frame, embedding towers re-run inside the minibatch, "
+                     "SN/apply.py:381-387,440-446), %.1f s" % (n, dt)}
+    # samples below (n-2)*160 depend only on frames < n
+    k = max((n - 2) * spec.HOP, 0)
+    cw = out["denoised_wav"].numpy()[:k]
+    rms = float(np.sqrt(np.mean((cw - hip_wav[:k]) ** 2))) if k else None
+    return res, rms
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+
+    W = weights.synthetic_weights(a.kind, 7)
+    eng = engine.Engine(a.kind, W, device=local, frames_per_chunk=a.frames_per_chunk or None)
+    mixes, ca, cb = make_batch(a.kind, rank, a.clips_per_gpu, a.seconds)
+    mix_t, mix_off = eng._dev(mixes)
+    ca_t, ca_off = eng._dev(ca)
+    cb_t, cb_off = eng._dev(cb)
+    frames = sum(spec.frames_for_samples(len(m))[1] for m in mixes)
+    audio_s = sum(len(m) for m in mixes) / float(spec.FS)
+    gathered = None
+    if world > 1:
+        gathered = torch.empty(world * mix_off[-1], dtype=torch.float32, device=dev)
+
+    def step():
+        res = eng.enhance_device(mix_t, mix_off, ca_t, ca_off, cb_t, cb_off)
+        if world > 1:       # the path's one exchange step: reassemble the batch
+            dist.all_gather_into_tensor(gathered, res["denoised_wav"])
+        return res
+
+    for _ in range(a.warmup):
+        res = step()
+    torch.cuda.synchronize()
+    eng.set_option("profile", 1)
+    eng.profile_reset()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        res = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    prof = eng.profile()
+    eng.set_option("profile", 0)
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        conv = prof.get("conv_igemm_f32", {"ms": 0.0, "flops": 0.0, "calls": 0})
+        tflops = conv["flops"] / (conv["ms"] * 1e-3) / 1e12 if conv["ms"] > 0 else 0.0
+        stft = prof.get("stft_features", {"ms": 0.0, "bytes": 0.0})
+        istft = prof.get("istft_ola", {"ms": 0.0, "bytes": 0.0})
+        gbs = lambda e: e["bytes"] / (e["ms"] * 1e-3) / 1e9 if e["ms"] > 0 else 0.0
+        line = {
+            "metric": "denoised audio seconds per second (16 kHz), whole job",
+            "value": world * audio_s * a.steps / dt,
+            "unit": "audio-seconds/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": 1e3 * dt / a.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "%d x %.0f s 16 kHz synthetic mixture(s) per GPU, %s model, STFT+embed+mask+iSTFT end-to-end%s"
+                                   % (a.clips_per_gpu, a.seconds, a.kind, " + RCCL all-gather" if world > 1 else ""),
+                       "clips_per_gpu": a.clips_per_gpu, "frames_per_gpu": frames, "weights": "synthetic seed 7",
+                       "parallelism": "clip-sharded x%d" % world},
+            "frames_per_s": world * frames * a.steps / dt,
+            "x_realtime_per_gpu": audio_s * a.steps / dt,
+            "roofline": {"bound": "mfma", "kernel": "conv_igemm_f32", "achieved": tflops, "peak": F32_MFMA_PEAK_TFLOPS,
+                         "unit": "TFLOP/s", "frac": tflops / F32_MFMA_PEAK_TFLOPS, "traffic": None,
+                         "launches": conv["calls"], "kernel_ms_per_step": conv["ms"] / a.steps},
+            "hbm_kernels": {"stft_features_GBs": gbs(stft), "istft_ola_GBs": gbs(istft), "peak_GBs": HBM_PEAK_GBS},
+            "kernel_ms_per_step": {k: v["ms"] / a.steps for k, v in prof.items()},
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            hip_wav = res["denoised_wav"][:mix_off[1]].cpu().numpy()
+            base, rms = cpu_baseline(W, a.kind, mixes[0], ca[0], cb[0], a.cpu_frames, hip_wav, a.cpu_threads)
+            line["cpu_baseline"] = base
+            line["rms_vs_cpu_f32"] = rms
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+    eng.close()
+
+
+if __name__ == "__main__":
+    main()

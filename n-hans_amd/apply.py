@@ -1,0 +1,239 @@
+"""Drop-in API surface of N-HANS inference on MI355X.
+
+Mirrors the reference's entry points -- same names, argument meaning, file outputs and error
+behaviour -- with the TensorFlow graph calls replaced by the HIP library (engine.Engine):
+
+    apply_snc(mixedpath, pospath, negpath, save_to)        SN/apply.py:339-472
+    apply_denoiser(mixedpath, negpath, save_to)            SN/apply.py:478-481
+    apply_separator(mixedpath, cleanpath, noisepath, save_to)   SS/apply.py:288-397
+    main() for the `nhans_denoiser` / `nhans_separator` console scripts   setup.py:44-50,
+        flags --input --neg --pos --output --compensate --ac            SN/apply.py:29-35
+
+Host code here is I/O only: wav reading/normalising/trimming (numpy, float64 like the reference),
+writing float32 wavs, and the denoiser's removed/compensated side outputs.
+
+Deviations that the tree forces (documented in DESIGN.md):
+  * Conditioning recordings shorter than 200 frames (32,240 samples) crash the in-tree reference
+    (`tf.reshape(..., [200, 201])`, SN/apply.py:381-382) although its own examples are 1 s long.
+    They are repeated to the needed length with the reference's own repeat rule for short noise
+    (`domixing`, SN/apply.py:60-66).
+  * `./audio_examples/Silent.wav` (default --pos) is all zeros; if the file is absent an all-zero
+    recording is used.
+  * Weights: `./trained_model/<bundle>` relative to the CWD as in the reference (or
+    $NHANS_MODEL_DIR).  The bundles in the reference tree are git-LFS pointers; loading one raises
+    unless synthetic weights are requested explicitly (--weights synthetic / NHANS_WEIGHTS=synthetic).
+"""
+import argparse
+import os
+import sys
+
+import numpy as np
+from scipy.io.wavfile import read as wavread
+from scipy.io.wavfile import write as wavwrite
+
+from . import spec
+
+Fs = spec.FS
+Noise_Win = spec.NOISE_WIN
+Mix_Win = spec.MIX_WIN
+
+DENOISER_BUNDLE = "81448_0-1000000"      # SN/apply.py:431-432
+SEPARATOR_BUNDLE = "81457_2-545000"      # SS/apply.py:371-372
+
+_engines = {}
+
+
+class Flags(object):
+    """Stand-in for the reference's absl FLAGS (SN/apply.py:29-35)."""
+    input = "./audio_examples/mixed.wav"
+    neg = "./audio_examples/game_noise.wav"
+    pos = "./audio_examples/Silent.wav"
+    output = "./audio_examples/denoised.wav"
+    compensate = 0.0
+    ac = False
+    Fs = Fs
+    weights = os.environ.get("NHANS_WEIGHTS", "checkpoint")
+    model_dir = os.environ.get("NHANS_MODEL_DIR", "./trained_model")
+
+
+FLAGS = Flags()
+
+
+# ------------------------------------------------------------------------------ wav front end
+def read_wav(in_path):
+    """SN/apply.py:46-53."""
+    rate, samples = wavread(in_path)
+    assert rate == FLAGS.Fs
+    assert samples.dtype == 'int16'
+    if len(samples.shape) > 1:
+        samples = samples.mean(axis=1)
+    assert len(samples.shape) == 1
+    return samples
+
+
+def normalise(samples):
+    """x / (max(abs(x)) + 1e-6) in float64 -> float32 (SN/apply.py:150-155); int16 abs wraps like
+    the reference's."""
+    with np.errstate(over="ignore"):
+        peak = np.max(np.abs(samples)) if len(samples) else 0
+    return (samples / (peak + 0.000001)).astype(np.float32)
+
+
+def trim_to_frames(samples):
+    """Cut the end to have an exact number of frames (SN/apply.py:158-161)."""
+    win_samples = int(FLAGS.Fs * 0.025)
+    hop_samples = int(FLAGS.Fs * 0.010)
+    if (len(samples) - win_samples) % hop_samples != 0:
+        samples = samples[:-((len(samples) - win_samples) % hop_samples)]
+    return samples
+
+
+def extend_context(samples):
+    """Short-context policy: repeat the recording until it yields Noise_Win frames, with the
+    reference's repeat rule for noise shorter than speech (SN/apply.py:60-66)."""
+    need = spec.MIN_CTX_SAMPLES
+    if len(samples) == 0:
+        return np.zeros(need, dtype=samples.dtype)
+    out = samples
+    while need - len(out) > 0:
+        out = np.concatenate([out, samples[:need - len(out)]], axis=0)
+    return out
+
+
+def handle_signals(mixedpath, noisepospath, noisenegpath):
+    """SN/apply.py:142-167: returns (pos, neg, mixed) float32; wav problems print
+    'error in threads' and yield None, like the reference's bare except."""
+    try:
+        mixedsamples = read_wav(mixedpath)
+        noisepossamples = _read_context(noisepospath)
+        noisenegsamples = _read_context(noisenegpath)
+        mixedsamples = trim_to_frames(normalise(mixedsamples))
+        return normalise(noisepossamples), normalise(noisenegsamples), mixedsamples
+    except Exception:
+        print('error in threads')
+        print(mixedpath, noisepospath, noisenegpath)
+        return None
+
+
+def _read_context(path):
+    if path is None or (os.path.basename(path) == "Silent.wav" and not os.path.exists(path)):
+        return np.zeros(spec.MIN_CTX_SAMPLES, dtype=np.int16)
+    return extend_context(read_wav(path))
+
+
+# ------------------------------------------------------------------------------ engine / weights
+def _load_weights(kind):
+    from . import weights
+    if FLAGS.weights == "synthetic":
+        return weights.synthetic_weights(kind, 7)
+    bundle = DENOISER_BUNDLE if kind == spec.DENOISER else SEPARATOR_BUNDLE
+    return weights.load_checkpoint(os.path.join(FLAGS.model_dir, bundle), kind)
+
+
+def get_engine(kind):
+    if kind not in _engines:
+        from . import engine
+        _engines[kind] = engine.Engine(kind, _load_weights(kind))
+    return _engines[kind]
+
+
+def set_engine(kind, eng):
+    """Install a pre-built engine (tests, benchmarks, multi-GPU drivers)."""
+    _engines[kind] = eng
+
+
+# ------------------------------------------------------------------------------ apply_*
+def _enhance_files(kind, mixedpath, ctx_a_path, ctx_b_path):
+    """-> (denoised_samples, mixed_processed_samples) float32 for one file triple; ctx order is
+    resnet_block argument order."""
+    sig = handle_signals(mixedpath, ctx_a_path, ctx_b_path)
+    if sig is None:
+        raise RuntimeError("could not read %s / %s / %s" % (mixedpath, ctx_a_path, ctx_b_path))
+    ca, cb, mixed = sig
+    res = get_engine(kind).enhance([mixed], [ca], [cb], want_mixed=True)
+    return res["denoised_wav"][0], res["mixed_wav"][0]
+
+
+def apply_snc(mixedpath, pospath, negpath, save_to):
+    """Selective noise suppression: keep `pos`-like noise, remove `neg`-like noise
+    (SN/apply.py:339-472).  Writes save_to plus the *mixed_processed / *removed / *compensated
+    side files named by the reference's save_to[:-12] rule."""
+    denoised_samples, mixed_samples = _enhance_files(spec.DENOISER, mixedpath, pospath, negpath)
+    wavwrite(save_to, FLAGS.Fs, denoised_samples)
+    wavwrite(save_to[:-12] + 'mixed_processed.wav', FLAGS.Fs, mixed_samples)
+    removed_samples = mixed_samples - denoised_samples
+    wavwrite(save_to[:-12] + 'removed.wav', FLAGS.Fs, removed_samples)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        snr_est = np.mean(np.square(denoised_samples)) / np.mean(np.square(removed_samples))
+    print(snr_est)
+    print('---------------------------')
+    if not FLAGS.ac:
+        compensation_factor = FLAGS.compensate
+    else:
+        compensation_factor = snr_est / 20
+    compensated_samples = denoised_samples + removed_samples * compensation_factor
+    wavwrite(save_to[:-12] + 'compensated.wav', FLAGS.Fs, compensated_samples.astype(np.float32))
+
+
+def apply_denoiser(mixedpath, negpath, save_to):
+    """SN/apply.py:478-481: plain denoising = selective suppression with a silent positive."""
+    dir = './audio_examples/'
+    pospath = dir + 'Silent.wav'
+    apply_snc(mixedpath, pospath, negpath, save_to)
+
+
+def apply_separator(mixedpath, cleanpath, noisepath, save_to):
+    """SS/apply.py:288-397: keep the `cleanpath` (target, --pos) speaker, remove the `noisepath`
+    (interferer, --neg) speaker.  resnet_block order is (noise, clean), SS/main.py:205-242."""
+    denoised_samples, mixed_samples = _enhance_files(spec.SEPARATOR, mixedpath, noisepath, cleanpath)
+    wavwrite(save_to, FLAGS.Fs, denoised_samples)
+    wavwrite(save_to[:-12] + 'mixed_processed.wav', FLAGS.Fs, mixed_samples)
+
+
+# ------------------------------------------------------------------------------ CLI
+def _parse(argv, prog):
+    p = argparse.ArgumentParser(prog=prog)
+    p.add_argument('--input', default=FLAGS.input)
+    p.add_argument('--neg', default=FLAGS.neg)
+    p.add_argument('--pos', default=FLAGS.pos)
+    p.add_argument('--output', default=FLAGS.output)
+    p.add_argument('--compensate', type=float, default=0.0)
+    p.add_argument('--ac', action='store_true')
+    p.add_argument('--weights', default=FLAGS.weights, choices=['checkpoint', 'synthetic'])
+    p.add_argument('--model_dir', default=FLAGS.model_dir)
+    a = p.parse_args(argv)
+    for k, v in vars(a).items():
+        setattr(FLAGS, k, v)
+    return a
+
+
+def _pairs(a):
+    """File mode or directory mode: in directory mode inputs and conditioning recordings are
+    paired by identical file name (README.md:59-66)."""
+    if os.path.isdir(a.input):
+        os.makedirs(a.output, exist_ok=True)
+        for name in sorted(os.listdir(a.input)):
+            if not name.lower().endswith('.wav'):
+                continue
+            pick = lambda d: os.path.join(d, name) if os.path.isdir(d) else d
+            yield os.path.join(a.input, name), pick(a.pos), pick(a.neg), os.path.join(a.output, name)
+    else:
+        yield a.input, a.pos, a.neg, a.output
+
+
+def main(argv=None):
+    """`nhans_denoiser` (setup.py:46)."""
+    a = _parse(argv, 'nhans_denoiser')
+    for mixed, pos, neg, out in _pairs(a):
+        apply_snc(mixed, pos, neg, out)
+
+
+def main_separator(argv=None):
+    """`nhans_separator` (setup.py:48)."""
+    a = _parse(argv, 'nhans_separator')
+    for mixed, pos, neg, out in _pairs(a):
+        apply_separator(mixed, pos, neg, out)
+
+
+if __name__ == '__main__':
+    main(sys.argv[1:])

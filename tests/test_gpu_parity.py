@@ -1,0 +1,252 @@
+"""Parity of the HIP path (through the C ABI) against the float64 oracle and the committed golden
+vectors, on a real MI355X.  Tolerances (BASELINE.json north_star): mask logits <= 1e-4 max-abs,
+reconstructed waveform <= 1e-3 RMS; features are compared in the linear-magnitude domain
+(|X| within 1e-5 * max|X|) because log(|X|+1e-5) amplifies float32 FFT rounding at silent bins.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import nhans_amd  # noqa: F401
+from nhans_amd import apply, engine, spec, synth
+from oracle import nhans_oracle as O
+from conftest import GOLDEN, load_case
+
+pytestmark = pytest.mark.gpu
+
+LOGIT_TOL = 1e-4
+WAV_RMS_TOL = 1e-3
+
+
+@pytest.fixture(scope="module")
+def eng_d(lib_built, weights_denoiser):
+    e = engine.Engine("denoiser", weights_denoiser)
+    yield e
+    e.close()
+
+
+@pytest.fixture(scope="module")
+def eng_s(lib_built, weights_separator):
+    e = engine.Engine("separator", weights_separator)
+    yield e
+    e.close()
+
+
+def exp2_inputs():
+    mix = apply.trim_to_frames(apply.normalise(apply.read_wav(os.path.join(GOLDEN, "exp2_noisy.wav"))))
+    return mix, apply.normalise(synth.silent()), apply.normalise(synth.noise_context(0))
+
+
+def test_native_library_is_loaded(eng_d):
+    maps = open("/proc/self/maps").read()
+    assert "libnhans_hip.so" in maps
+
+
+def test_stft_features_exp2(eng_d):
+    g = load_case("case_exp2")
+    mix, _, _ = exp2_inputs()
+    lm, ph = eng_d.stft_features(torch.from_numpy(mix).cuda(), [0, len(mix)])
+    lm, ph = lm.cpu().numpy().astype(np.float64), ph.cpu().numpy().astype(np.float64)
+    assert lm.shape == (308, 201)
+    ref = O.stft(mix)
+    z = (np.exp(lm) - 1e-5) * np.exp(1j * ph)
+    assert np.abs(z - ref).max() <= 1e-5 * np.abs(ref).max()
+    zg = (np.exp(g["logmag"].astype(np.float64)) - 1e-5) * np.exp(1j * g["phase"].astype(np.float64))
+    assert np.abs(z - zg).max() <= 2e-5 * np.abs(ref).max()
+    # log domain: loose bound only (silent bins), tight where there is energy
+    loud = np.abs(ref) > 1e-2
+    assert np.abs(lm - np.log(np.abs(ref) + 1e-5))[loud].max() < 2e-4
+
+
+def test_context_features_truncate_to_200_frames_and_short_context_errors(eng_d):
+    ca, cb = apply.normalise(synth.silent()), apply.normalise(synth.noise_context(2))
+    cat = torch.from_numpy(np.concatenate([ca, cb])).cuda()
+    lm, _ = eng_d.stft_features(cat, [0, len(ca), len(ca) + len(cb)], 200, False)
+    lm = lm.cpu().numpy().reshape(2, 200, 201)
+    assert np.abs(lm[0] - np.log(1e-5)).max() < 1e-5                      # Silent -> ln(1e-5)
+    ref, _ = O.logmag_phase(O.stft(cb))
+    assert np.abs(np.exp(lm[1]) - np.exp(ref[:200])).max() < 1e-4
+    short = torch.zeros(16000).cuda()
+    with pytest.raises(Exception, match="frames"):
+        eng_d.stft_features(short, [0, 16000], 200, False)
+
+
+def test_embedding_tower(eng_d, weights_denoiser):
+    g = load_case("case_exp2")
+    _, ca, cb = exp2_inputs()
+    ctx = np.stack([O.context(O.logmag_phase(O.stft(w))[0]) for w in (ca, cb)])
+    emb = eng_d.embed(torch.from_numpy(ctx.astype(np.float32)).cuda()).cpu().numpy()
+    assert np.abs(emb[0] - g["emb_a"]).max() < 2e-5 and np.abs(emb[1] - g["emb_b"]).max() < 2e-5
+    # batch-size / chunk independence, bit for bit
+    eng_d.set_option("contexts_per_chunk", 1)
+    emb1 = eng_d.embed(torch.from_numpy(ctx.astype(np.float32)).cuda()).cpu().numpy()
+    eng_d.set_option("contexts_per_chunk", 64)
+    assert np.array_equal(emb, emb1)
+
+
+def test_block_outputs_and_logits_exp2(eng_d):
+    """Same feature tensor into oracle and kernel (the golden log-magnitudes), per-block and logits."""
+    g = load_case("case_exp2")
+    lm = torch.from_numpy(g["logmag"]).cuda()
+    ea = torch.from_numpy(g["emb_a"][None]).cuda()
+    eb = torch.from_numpy(g["emb_b"][None]).cuda()
+    tf = [int(f) for f in g["tap_frames"]]
+    for b in range(9):
+        got = torch.cat([eng_d.block_output(lm, [0, 308], ea, eb, f, 1, b) for f in tf]).cpu().numpy()
+        ref = g["block%d" % b]
+        sub = got.reshape(-1)[::97]
+        assert sub.shape == ref.shape
+        assert np.abs(sub - ref).max() < 1e-4 * max(1.0, np.abs(ref).max()), "block %d" % b
+    lg, den = eng_d.mask_net(lm, [0, 308], ea, eb)
+    lg, den = lg.cpu().numpy(), den.cpu().numpy()
+    assert np.abs(lg - g["logits"]).max() < LOGIT_TOL
+    assert np.abs(den - (g["logmag"] + g["logits"])).max() < LOGIT_TOL
+
+
+def test_end_to_end_waveform_exp2(eng_d):
+    g = load_case("case_exp2")
+    mix, ca, cb = exp2_inputs()
+    out = eng_d.enhance([mix], [ca], [cb], want_mixed=True, taps=True)
+    w = out["denoised_wav"][0]
+    assert w.dtype == np.float32 and w.shape == (49520,)
+    assert np.sqrt(np.mean((w - g["denoised_wav"]) ** 2)) < WAV_RMS_TOL
+    assert np.sqrt(np.mean((out["mixed_wav"][0] - g["mixed_wav"]) ** 2)) < WAV_RMS_TOL
+    assert np.abs(out["logits"] - g["logits"]).max() < 5 * LOGIT_TOL     # features differ at silent bins
+    assert np.abs(out["emb"][1] - g["emb_b"]).max() < 1e-4
+
+
+def test_ten_second_clip_selected_frames(eng_d):
+    g = load_case("case_synth10s")
+    lm = torch.from_numpy(g["logmag"]).cuda()
+    assert g["logmag"].shape == (998, 201)
+    ea = torch.from_numpy(g["emb_a"][None]).cuda()
+    eb = torch.from_numpy(g["emb_b"][None]).cuda()
+    lg, _ = eng_d.mask_net(lm, [0, 998], ea, eb)
+    fr = g["frames"]
+    assert np.abs(lg.cpu().numpy()[fr] - g["logits"]).max() < LOGIT_TOL
+
+
+def test_separator_model(eng_s):
+    g = load_case("case_separator")
+    mix = apply.trim_to_frames(apply.normalise(synth.mixture(3, 2.0)))
+    ca = apply.normalise(synth.speaker_context(3, low=False))
+    cb = apply.normalise(synth.speaker_context(3, low=True))
+    out = eng_s.enhance([mix], [ca], [cb], want_mixed=False, taps=True)
+    assert np.abs(out["emb"][0] - g["emb_a"]).max() < 1e-4 and np.abs(out["emb"][1] - g["emb_b"]).max() < 1e-4
+    lm = torch.from_numpy(g["logmag"]).cuda()
+    lg, _ = eng_s.mask_net(lm, [0, lm.shape[0]], torch.from_numpy(g["emb_a"][None]).cuda(),
+                           torch.from_numpy(g["emb_b"][None]).cuda())
+    assert np.abs(lg.cpu().numpy()[g["frames"]] - g["logits"]).max() < LOGIT_TOL
+    i = list(g["tap_frames"])[0]
+    b7 = eng_s.block_output(lm, [0, lm.shape[0]], torch.from_numpy(g["emb_a"][None]).cuda(),
+                            torch.from_numpy(g["emb_b"][None]).cuda(), int(i), 1, 7).cpu().numpy()
+    assert np.abs(b7.reshape(-1)[::97] - g["block7"]).max() < 1e-3
+
+
+def test_ragged_batch_edges_and_shard_invariance(eng_d):
+    """1-, 2- and 98-frame clips in one batch: window zero padding at both clip ends, no leakage
+    between neighbouring clips, and batch == one-by-one, bit for bit."""
+    g = load_case("case_ragged")
+    mixes, cas, cbs = [], [], []
+    for i, n in enumerate(g["lens"]):
+        mixes.append(apply.trim_to_frames(apply.normalise(synth.mixture(10 + i, int(n) / 16000.0))))
+        cas.append(apply.normalise(synth.silent()))
+        cbs.append(apply.normalise(synth.noise_context(10 + i)))
+    assert [len(m) for m in mixes] == [400, 560, 16000]
+    batch = eng_d.enhance(mixes, cas, cbs, want_mixed=False, taps=True)
+    foff = [0, 1, 3, 101]
+    for i in range(3):
+        lg = batch["logits"][foff[i]:foff[i + 1]]
+        # logits given the kernel's own features: allow the silent-bin feature difference
+        assert np.abs(lg - g["logits_%d" % i]).max() < 5 * LOGIT_TOL, i
+        assert np.sqrt(np.mean((batch["denoised_wav"][i] - g["denoised_wav_%d" % i]) ** 2)) < WAV_RMS_TOL
+        single = eng_d.enhance([mixes[i]], [cas[i]], [cbs[i]], want_mixed=False, taps=True)
+        assert np.array_equal(single["logits"], lg)
+        assert np.array_equal(single["denoised_wav"][0], batch["denoised_wav"][i])
+    # fake-rank mode: 2 logical shards on one device == the whole batch
+    from nhans_amd import dist as nd
+    parts = []
+    for r in range(2):
+        lo, hi = nd.shard_bounds(3, 2, r)
+        parts += eng_d.enhance(mixes[lo:hi], cas[lo:hi], cbs[lo:hi], want_mixed=False)["denoised_wav"]
+    assert all(np.array_equal(a, b) for a, b in zip(parts, batch["denoised_wav"]))
+
+
+def test_chunking_is_invisible(eng_d):
+    mix = apply.trim_to_frames(apply.normalise(synth.mixture(21, 1.5)))
+    ca, cb = apply.normalise(synth.silent()), apply.normalise(synth.noise_context(21))
+    a = eng_d.enhance([mix], [ca], [cb], want_mixed=False, taps=True)
+    eng_d.set_option("frames_per_chunk", 37)
+    b = eng_d.enhance([mix], [ca], [cb], want_mixed=False, taps=True)
+    eng_d.set_option("frames_per_chunk", 1024)
+    assert np.array_equal(a["logits"], b["logits"]) and np.array_equal(a["denoised_wav"][0], b["denoised_wav"][0])
+
+
+def test_full_size_properties_10s(eng_d):
+    """BASELINE size (10 s, 998 frames): size-independent properties instead of a full oracle run."""
+    mix = apply.trim_to_frames(apply.normalise(synth.mixture(0, 10.0)))
+    ca, cb = apply.normalise(synth.silent()), apply.normalise(synth.noise_context(0))
+    a = eng_d.enhance([mix], [ca], [cb], want_mixed=True, taps=True)
+    b = eng_d.enhance([mix], [ca], [cb], want_mixed=True, taps=True)
+    assert a["logits"].shape == (998, 201) and len(a["denoised_wav"][0]) == 159920
+    assert np.array_equal(a["denoised_wav"][0], b["denoised_wav"][0])            # deterministic
+    # STFT -> iSTFT of the unmodified spectrum is the identity in the interior (up to the 1e-5 floor)
+    rt = a["mixed_wav"][0]
+    assert np.abs(rt[240:-240] - mix[240:-240]).max() < 2e-4
+    assert abs(rt[0]) < 1e-6
+    # denoised = mixed_central + out, frame by frame
+    g = load_case("case_synth10s")
+    assert np.abs(a["logits"][g["frames"]] - g["logits"]).max() < 5 * LOGIT_TOL
+    assert np.isfinite(a["denoised_wav"][0]).all()
+
+
+def test_istft_matches_oracle_and_is_linear_in_magnitude(eng_d):
+    rng = np.random.default_rng(5)
+    T = 57
+    lm = rng.normal(-2, 1.5, (T, 201)).astype(np.float32)
+    ph = rng.uniform(-np.pi, np.pi, (T, 201)).astype(np.float32)
+    w, off = eng_d.istft(torch.from_numpy(lm).cuda(), torch.from_numpy(ph).cuda(), [0, 20, 57])
+    w = w.cpu().numpy()
+    assert off == [0, 19 * 160 + 400, 19 * 160 + 400 + 36 * 160 + 400]
+    r0 = O.recover_samples(lm[:20].astype(np.float64), ph[:20].astype(np.float64))
+    r1 = O.recover_samples(lm[20:].astype(np.float64), ph[20:].astype(np.float64))
+    assert np.abs(w[:off[1]] - r0).max() < 2e-5 and np.abs(w[off[1]:] - r1).max() < 2e-5
+    w2, _ = eng_d.istft(torch.from_numpy(lm + np.float32(np.log(2.0))).cuda(), torch.from_numpy(ph).cuda(), [0, 20, 57])
+    assert np.abs(w2.cpu().numpy() - 2 * w).max() < 2e-5                      # exp(lm + ln 2) = 2 exp(lm)
+
+
+def test_apply_entry_points_write_reference_files(eng_d, eng_s, tmp_path, capsys):
+    from scipy.io import wavfile
+    apply.set_engine("denoiser", eng_d)
+    apply.set_engine("separator", eng_s)
+    neg = str(tmp_path / "neg.wav")
+    wavfile.write(neg, 16000, synth.noise_context(0)[:16000])                 # 1 s: short-context policy
+    out = str(tmp_path / "exp2_denoised.wav")
+    cwd = os.getcwd()
+    os.chdir(tmp_path)
+    try:
+        apply.apply_denoiser(os.path.join(GOLDEN, "exp2_noisy.wav"), neg, out)
+    finally:
+        os.chdir(cwd)
+    rate, w = wavfile.read(out)
+    assert rate == 16000 and w.dtype == np.float32 and len(w) == 49520      # == shipped exp2_denoised.wav geometry
+    for side in ("mixed_processed.wav", "removed.wav", "compensated.wav"):
+        r, s = wavfile.read(str(tmp_path / ("exp2_" + side)))
+        assert r == 16000 and len(s) == 49520 and s.dtype == np.float32
+    _, mixed = wavfile.read(str(tmp_path / "exp2_mixed_processed.wav"))
+    _, removed = wavfile.read(str(tmp_path / "exp2_removed.wav"))
+    _, comp = wavfile.read(str(tmp_path / "exp2_compensated.wav"))
+    assert np.array_equal(removed, mixed - w) and np.array_equal(comp, w)   # compensate = 0
+    assert "---------------------------" in capsys.readouterr().out         # prints snr_est like the reference
+    # separator + CLI
+    mixp, posp, negp = [str(tmp_path / n) for n in ("m.wav", "p.wav", "n.wav")]
+    wavfile.write(mixp, 16000, synth.mixture(3, 1.0))
+    wavfile.write(posp, 16000, synth.speaker_context(3, low=False))
+    wavfile.write(negp, 16000, synth.speaker_context(3, low=True))
+    sep = str(tmp_path / "sep_denoised.wav")
+    apply.main_separator(["--input", mixp, "--pos", posp, "--neg", negp, "--output", sep, "--weights", "synthetic"])
+    r, s = wavfile.read(sep)
+    assert r == 16000 and s.dtype == np.float32 and len(s) == 15920
+    assert os.path.exists(str(tmp_path / "sep_mixed_processed.wav"))

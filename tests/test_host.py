@@ -1,0 +1,207 @@
+"""CPU tests of the host side: checkpoint inventory and bundle reader, folding/packing, the
+apply_* front end, the C-ABI library's exported surface (no compute without a GPU), the FFT
+building blocks compiled for the host."""
+import ctypes
+import json
+import os
+import re
+import struct
+import subprocess
+
+import numpy as np
+import pytest
+from scipy.io import wavfile
+
+import nhans_amd  # noqa: F401
+from nhans_amd import apply, fold, hip, spec, synth, tfbundle, weights
+from conftest import GOLDEN, ROOT
+
+
+# ------------------------------------------------------------------------------ inventory / bundle
+@pytest.mark.parametrize("kind", ["denoiser", "separator"])
+def test_inventory_matches_shipped_index(kind):
+    ent = tfbundle.read_index(os.path.join(GOLDEN, kind + ".index"))
+    want = json.load(open(os.path.join(GOLDEN, "checkpoint_index.json")))[kind]
+    assert [[k, list(v["shape"]), v["dtype"], v["offset"], v["size"]] for k, v in ent.items()] == want
+    shapes = spec.variable_shapes(kind)
+    extra = set(ent) - set(shapes)
+    assert extra == (set() if kind == "denoiser" else {"Variable"})       # SS global_step
+    for n, s in shapes.items():
+        assert tuple(ent[n]["shape"]) == tuple(s) and ent[n]["dtype"] == tfbundle.DT_FLOAT
+    assert sum(int(np.prod(s)) for s in shapes.values()) == 28999881
+    assert max(e["offset"] + e["size"] for e in ent.values()) == (115999524 if kind == "denoiser" else 115999528)
+
+
+def test_bundle_reader_roundtrip_and_lfs_pointer(tmp_path, weights_separator):
+    """Write a data shard laid out by the shipped separator index, read it back."""
+    prefix = str(tmp_path / "81457_2-545000")
+    idx = os.path.join(GOLDEN, "separator.index")
+    os.symlink(idx, prefix + ".index")
+    ent = tfbundle.read_index(idx)
+    with open(prefix + ".data-00000-of-00001", "wb") as f:
+        f.write(b"version https://git-lfs.github.com/spec/v1\noid sha256:0\nsize 1\n")
+    with pytest.raises(FileNotFoundError):
+        weights.load_checkpoint(prefix, "separator")
+    buf = bytearray(max(e["offset"] + e["size"] for e in ent.values()))
+    for n, e in ent.items():
+        if n == "Variable":
+            buf[e["offset"]:e["offset"] + 4] = struct.pack("<i", 545000)
+        else:
+            buf[e["offset"]:e["offset"] + e["size"]] = weights_separator[n].tobytes()
+    with open(prefix + ".data-00000-of-00001", "wb") as f:
+        f.write(buf)
+    got = weights.load_checkpoint(prefix, "separator")
+    assert list(got) == list(spec.variable_shapes("separator"))
+    for n in got:
+        assert np.array_equal(got[n], weights_separator[n])
+    assert int(tfbundle.load_checkpoint(prefix)["Variable"]) == 545000
+
+
+def test_synthetic_weights_deterministic_and_shared():
+    a = weights.synthetic_weights("denoiser", 7)
+    b = weights.synthetic_weights("denoiser", 7)
+    s = weights.synthetic_weights("separator", 7)
+    assert all(np.array_equal(a[k], b[k]) for k in a)
+    assert np.array_equal(a["resblock3_1_conv2/w"], s["resblock3_1_conv2/w"])
+    assert "resblock1_1_conv1_noise_pos_emb/w" in a and "resblock1_1_conv1_clean_emb/w" in s
+    assert not np.array_equal(a["last_dense/w"], weights.synthetic_weights("denoiser", 8)["last_dense/w"])
+
+
+# ------------------------------------------------------------------------------ folding
+def test_pack_igemm_layout():
+    rng = np.random.default_rng(0)
+    k, n, npad = 64, 40, 64
+    w = rng.standard_normal((k, n))
+    p = fold.pack_igemm(w, npad).reshape(k // 32, npad // 32, 4, 64, 4)
+    for chunk, nt, q, lane, e in [(0, 0, 0, 0, 0), (1, 1, 3, 63, 3), (1, 0, 2, 37, 1), (0, 1, 1, 5, 2)]:
+        kk = 32 * chunk + 8 * q + 4 * (lane >> 5) + e
+        nn = 32 * nt + (lane & 31)
+        want = np.float32(w[kk, nn]) if nn < n else np.float32(0)
+        assert p[chunk, nt, q, lane, e] == want
+
+
+def test_fold_blob_structure(weights_denoiser):
+    arrs = fold.fold_arrays(weights_denoiser, "denoiser")
+    assert arrs["cond.w"].size == 1024 * 3840 and arrs["cond.base"].size == 3840
+    assert arrs["m0.c1.w"].size == 16 * 64 and arrs["t0.c1.w"].size == 32 * 64
+    assert arrs["m2.c2.wpk_t"].size == 64 * 128 and "m1.c2.wpk_t" not in arrs
+    assert arrs["head.dense.wpk"].size == 13312 * 256
+    assert arrs["m0.c1.ts"].size == 35 * 64 and arrs["m7.c2.fs"].size == 26 * 512
+    # BN scale really is folded: conv1 weights of block 1 equal w * gamma/sqrt(var+eps)
+    W = weights_denoiser
+    sc = (W["resblock1_2_conv1/gamma"].astype(np.float64) /
+          np.sqrt(W["resblock1_2_conv1/pop_variance"].astype(np.float64) + 1e-3)).reshape(-1)
+    w = W["resblock1_2_conv1/w"].astype(np.float64).reshape(-1, 64) * sc
+    np.testing.assert_array_equal(arrs["m1.c1.wpk"], fold.pack_igemm(w))
+    blob = fold.write_blob({"b": np.arange(5, dtype=np.float32), "a": np.ones(3, dtype=np.float32)})
+    magic, ver, n, total = struct.unpack_from("<8sIIQ", blob, 0)
+    assert (magic, ver, n, total) == (b"NHANSFW1", 1, 2, len(blob))
+    name, off, cnt = struct.unpack_from("<48sQQ", blob, 24)
+    assert name.rstrip(b"\0") == b"a" and off % 256 == 0 and cnt == 3
+    assert np.frombuffer(blob, np.float32, 3, off).tolist() == [1, 1, 1]
+
+
+# ------------------------------------------------------------------------------ apply front end
+def test_read_normalise_trim_on_reference_example():
+    x = apply.read_wav(os.path.join(GOLDEN, "exp2_noisy.wav"))
+    assert x.dtype == np.int16 and len(x) == 49600
+    y = apply.trim_to_frames(apply.normalise(x))
+    assert y.dtype == np.float32 and len(y) == 49520 and abs(np.abs(y).max() - 1.0) < 1e-6
+    from oracle import nhans_oracle as O
+    np.testing.assert_array_equal(y, O.trim_to_frames(O.normalise(O.read_wav(os.path.join(GOLDEN, "exp2_noisy.wav")))))
+
+
+def test_read_wav_rejects_wrong_format(tmp_path):
+    p = str(tmp_path / "a.wav")
+    wavfile.write(p, 8000, np.zeros(100, dtype=np.int16))
+    with pytest.raises(AssertionError):
+        apply.read_wav(p)
+    wavfile.write(p, 16000, np.zeros(100, dtype=np.float32))
+    with pytest.raises(AssertionError):
+        apply.read_wav(p)
+    wavfile.write(p, 16000, np.stack([np.full(50, 100, np.int16), np.full(50, 300, np.int16)], 1))
+    assert apply.read_wav(p).tolist() == [200.0] * 50                  # stereo -> mean
+    assert apply.handle_signals(str(tmp_path / "missing.wav"), p, p) is None   # 'error in threads'
+
+
+def test_short_context_policy(tmp_path):
+    x = np.arange(16000, dtype=np.int16)
+    y = apply.extend_context(x)
+    assert len(y) == spec.MIN_CTX_SAMPLES == 32240
+    assert np.array_equal(y[:16000], x) and np.array_equal(y[16000:32000], x) and np.array_equal(y[32000:], x[:240])
+    z = np.arange(40000, dtype=np.int16)
+    assert apply.extend_context(z) is z
+    assert spec.frames_for_samples(32240)[1] == 200
+
+
+def test_cli_flag_surface():
+    a = apply._parse(["--input", "i.wav", "--neg", "n.wav", "--output", "o_denoised.wav", "--ac", "--compensate", "0.5"],
+                     "nhans_denoiser")
+    assert (a.input, a.neg, a.output, a.ac, a.compensate) == ("i.wav", "n.wav", "o_denoised.wav", True, 0.5)
+    assert a.pos.endswith("Silent.wav")
+    assert list(apply._pairs(a)) == [("i.wav", a.pos, "n.wav", "o_denoised.wav")]
+    apply.FLAGS.ac, apply.FLAGS.compensate = False, 0.0
+
+
+def test_missing_checkpoint_fails_loudly(tmp_path, monkeypatch):
+    monkeypatch.setattr(apply.FLAGS, "weights", "checkpoint")
+    monkeypatch.setattr(apply.FLAGS, "model_dir", str(tmp_path))
+    with pytest.raises((FileNotFoundError, OSError)):
+        apply._load_weights("denoiser")
+
+
+# ------------------------------------------------------------------------------ C ABI surface
+def test_library_exports_every_declared_symbol(lib_built):
+    header = open(os.path.join(ROOT, "include", "nhans_hip.h")).read()
+    declared = sorted(set(re.findall(r"\b(nhans_[a-z_0-9]+)\s*\(", header)))
+    assert declared == sorted(hip.EXPORTS)
+    lib = ctypes.CDLL(hip.LIB_PATH)
+    for name in declared:
+        assert hasattr(lib, name), name
+    h = hip.load()
+    assert h.nhans_abi_version() == 1
+    assert h.nhans_num_frames(399) == 0 and h.nhans_num_frames(400) == 1 and h.nhans_num_frames(159920) == 998
+    bad = ctypes.create_string_buffer(b"x" * 64, 64)
+    out = ctypes.c_void_p()
+    assert h.nhans_create(0, bad, 64, 0, ctypes.byref(out)) == -1            # NHANS_EINVAL: bad magic
+    assert b"magic" in h.nhans_last_error()
+
+
+def test_no_cpu_fallback_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from nhans_amd import engine
+    with pytest.raises(hip.NhansError):
+        engine.Engine("denoiser", {})
+
+
+def test_product_code_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "n-hans_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "import oracle" not in src and "from oracle" not in src, f
+
+
+# ------------------------------------------------------------------------------ FFT blocks on the host
+def test_fft400_host_build_matches_numpy(tmp_path):
+    so = str(tmp_path / "libfft400_host.so")
+    subprocess.check_call(["g++", "-O2", "-shared", "-fPIC", "-o", so,
+                           os.path.join(ROOT, "n-hans_amd", "csrc", "fft400_host.cpp")])
+    lib = ctypes.CDLL(so)
+    rng = np.random.default_rng(1)
+    x = (rng.standard_normal(400) + 1j * rng.standard_normal(400)).astype(np.complex64)
+    out = np.zeros(400, np.complex64)
+    for inv in (0, 1):
+        lib.nhans_fft400_host(x.ctypes.data_as(ctypes.c_void_p), out.ctypes.data_as(ctypes.c_void_p), inv)
+        ref = np.fft.ifft(x.astype(np.complex128)) * 400 if inv else np.fft.fft(x.astype(np.complex128))
+        assert np.abs(out - ref).max() < 5e-6 * np.abs(ref).max()
+
+
+def test_synthetic_audio_is_deterministic():
+    a, b = synth.mixture(3, 0.5), synth.mixture(3, 0.5)
+    assert a.dtype == np.int16 and np.array_equal(a, b) and np.abs(a).max() == 32767
+    assert len(synth.noise_context(0)) == 48000 >= spec.MIN_CTX_SAMPLES
+    assert not np.array_equal(synth.mixture(4, 0.5), a)
