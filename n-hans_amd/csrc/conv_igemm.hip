@@ -23,6 +23,7 @@
 namespace nhans {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));   // native vector: selects stay in registers
 
 constexpr int BM = 128, BK = 32, LDA = 36;
 
@@ -65,65 +66,104 @@ __global__ void __launch_bounds__(256) conv_igemm_f32(const ConvArgs a) {
         }
     }
 
-    // per-segment row state
-    const float* rptr[4];
+    // per-segment row state (kept in scalars / constant-indexed arrays so it stays in registers)
+    int64_t roff0, roff1, roff2, roff3;
     int hi0[4], wi0[4];
     int seg = 0, kh = 0, kw = 0, c0 = 0, chunk_in_seg = 0;
-    int sH = 0, sW = 0, sC = 0, sKW = 0, sKH = 0;
-    const float* swpk = nullptr;
-    auto enter_segment = [&](int s) {
-        const ConvSeg& g = a.seg[s];
-        sH = g.H; sW = g.W; sC = g.C; sKW = g.KW; sKH = g.KH; swpk = g.wpk;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            if (rb[i] >= 0) {
-                hi0[i] = rho[i] * g.sh - g.pt;
-                wi0[i] = rwo[i] * g.sw - g.pl;
-                rptr[i] = g.src + (((int64_t)rb[i] * g.H + hi0[i]) * g.W + wi0[i]) * (int64_t)g.C + col4 * 4;
-            } else {
-                hi0[i] = -(1 << 28); wi0[i] = 0; rptr[i] = g.src;
-            }
-        }
-        kh = 0; kw = 0; c0 = 0; chunk_in_seg = 0;
-    };
+    int sH, sW, sC, sKW, sKH;
+    const float* swpk;
+    const float* ssrc;
 
-    float4 ra[4];
-    float4 rbv[BN / 32];
-    auto issue_loads = [&]() {
-        const int off = (kh * sW + kw) * sC + c0;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const bool ok = (unsigned)(hi0[i] + kh) < (unsigned)sH && (unsigned)(wi0[i] + kw) < (unsigned)sW;
-            ra[i] = ok ? *reinterpret_cast<const float4*>(rptr[i] + off) : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-        const float4* bsrc = reinterpret_cast<const float4*>(
-            swpk + ((size_t)chunk_in_seg * (a.N / 32) + nt0) * 1024);
-#pragma unroll
-        for (int j = 0; j < BN / 32; ++j) rbv[j] = bsrc[j * 256 + tid];
-    };
-    auto advance = [&]() {      // move the (seg, kh, kw, c0) cursor to the next chunk
-        ++chunk_in_seg;
-        c0 += BK;
-        if (c0 >= sC) {
-            c0 = 0;
-            if (++kw >= sKW) {
-                kw = 0;
-                if (++kh >= sKH) {
-                    ++seg;
-                    if (seg < a.nseg) enter_segment(seg);
-                }
-            }
-        }
-    };
-    auto store_lds = [&](int buf) {
-        float* Ab = As + buf * A_BUF;
-        float* Bb = Bs + buf * B_BUF;
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-            *reinterpret_cast<float4*>(Ab + ((tid >> 3) + 32 * i) * LDA + col4 * 4) = ra[i];
-#pragma unroll
-        for (int j = 0; j < BN / 32; ++j) *reinterpret_cast<float4*>(Bb + (j * 256 + tid) * 4) = rbv[j];
-    };
+#define NH_ROW(I, ROFF)                                                                            \
+    if (rb[I] >= 0) {                                                                              \
+        hi0[I] = rho[I] * g.sh - g.pt;                                                             \
+        wi0[I] = rwo[I] * g.sw - g.pl;                                                             \
+        ROFF = (((int64_t)rb[I] * g.H + hi0[I]) * g.W + wi0[I]) * (int64_t)g.C + col4 * 4;          \
+    } else {                                                                                       \
+        hi0[I] = -(1 << 28); wi0[I] = 0; ROFF = 0;                                                 \
+    }
+#define NH_ENTER_SEGMENT(S)                                                                        \
+    {                                                                                              \
+        const ConvSeg& g = a.seg[S];                                                               \
+        sH = g.H; sW = g.W; sC = g.C; sKW = g.KW; sKH = g.KH; swpk = g.wpk; ssrc = g.src;          \
+        NH_ROW(0, roff0) NH_ROW(1, roff1) NH_ROW(2, roff2) NH_ROW(3, roff3)                        \
+        kh = 0; kw = 0; c0 = 0; chunk_in_seg = 0;                                                  \
+    }
+
+    // Loads are unconditional (a padded / out-of-range tap reads the segment base instead) and the
+    // zero mask is applied when the registers are written to LDS: a select right after the load
+    // would force a wait on it before the MFMAs it is meant to overlap.
+#define NH_LOAD_A(I, ROFF, RA, ROK)                                                                \
+    ROK = (unsigned)(hi0[I] + kh) < (unsigned)sH && (unsigned)(wi0[I] + kw) < (unsigned)sW;       \
+    RA = *reinterpret_cast<const f32x4*>(ssrc + (ROK ? ROFF + off : (int64_t)0));
+#define NH_ISSUE_LOADS()                                                                           \
+    {                                                                                              \
+        const int off = (kh * sW + kw) * sC + c0;                                                  \
+        NH_LOAD_A(0, roff0, ra0, rok0) NH_LOAD_A(1, roff1, ra1, rok1)                              \
+        NH_LOAD_A(2, roff2, ra2, rok2) NH_LOAD_A(3, roff3, ra3, rok3)                              \
+        const f32x4* bsrc = reinterpret_cast<const f32x4*>(                                        \
+            swpk + ((size_t)chunk_in_seg * (a.N / 32) + nt0) * 1024);                              \
+        rb0v = bsrc[tid];                                                                          \
+        rb1v = bsrc[256 + tid];                                                                    \
+        if constexpr (BN == 128) { rb2v = bsrc[512 + tid]; rb3v = bsrc[768 + tid]; }               \
+    }
+
+#define NH_ADVANCE()                                                                               \
+    {                                                                                              \
+        ++chunk_in_seg;                                                                            \
+        c0 += BK;                                                                                  \
+        if (c0 >= sC) {                                                                            \
+            c0 = 0;                                                                                \
+            if (++kw >= sKW) {                                                                     \
+                kw = 0;                                                                            \
+                if (++kh >= sKH) {                                                                 \
+                    ++seg;                                                                         \
+                    if (seg < a.nseg) NH_ENTER_SEGMENT(seg)                                        \
+                }                                                                                  \
+            }                                                                                      \
+        }                                                                                          \
+    }
+
+#define NH_STORE_LDS(BUF)                                                                          \
+    {                                                                                              \
+        float* Ab_ = As + (BUF) * A_BUF;                                                           \
+        float* Bb_ = Bs + (BUF) * B_BUF;                                                           \
+        const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};                                                     \
+        float* Ar_ = Ab_ + (tid >> 3) * LDA + col4 * 4;                                            \
+        *reinterpret_cast<f32x4*>(Ar_) = rok0 ? ra0 : z4;                                          \
+        *reinterpret_cast<f32x4*>(Ar_ + 32 * LDA) = rok1 ? ra1 : z4;                               \
+        *reinterpret_cast<f32x4*>(Ar_ + 64 * LDA) = rok2 ? ra2 : z4;                               \
+        *reinterpret_cast<f32x4*>(Ar_ + 96 * LDA) = rok3 ? ra3 : z4;                               \
+        *reinterpret_cast<f32x4*>(Bb_ + tid * 4) = rb0v;                                           \
+        *reinterpret_cast<f32x4*>(Bb_ + (256 + tid) * 4) = rb1v;                                   \
+        if constexpr (BN == 128) {                                                                 \
+            *reinterpret_cast<f32x4*>(Bb_ + (512 + tid) * 4) = rb2v;                               \
+            *reinterpret_cast<f32x4*>(Bb_ + (768 + tid) * 4) = rb3v;                               \
+        }                                                                                          \
+    }
+
+#define NH_COMPUTE(BUF)                                                                            \
+    {                                                                                              \
+        const float* Ab_ = As + (BUF) * A_BUF + arow;                                              \
+        const float* Bb_ = Bs + (BUF) * B_BUF + bcol;                                              \
+        _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                            \
+            f32x4 av[TM], bv[TN];                                                                  \
+            _Pragma("unroll") for (int i = 0; i < TM; ++i)                                         \
+                av[i] = *reinterpret_cast<const f32x4*>(Ab_ + i * 32 * LDA + q * 8);               \
+            _Pragma("unroll") for (int j = 0; j < TN; ++j)                                         \
+                bv[j] = *reinterpret_cast<const f32x4*>(Bb_ + j * 1024 + q * 256);                 \
+            _Pragma("unroll") for (int i = 0; i < TM; ++i)                                         \
+                _Pragma("unroll") for (int j = 0; j < TN; ++j) {                                   \
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i].x, bv[j].x, acc[i][j], 0, 0, 0); \
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i].y, bv[j].y, acc[i][j], 0, 0, 0); \
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i].z, bv[j].z, acc[i][j], 0, 0, 0); \
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i].w, bv[j].w, acc[i][j], 0, 0, 0); \
+                }                                                                                  \
+        }                                                                                          \
+    }
+
+    f32x4 ra0, ra1, ra2, ra3, rb0v, rb1v, rb2v, rb3v;
+    bool rok0, rok1, rok2, rok3;
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -136,72 +176,110 @@ __global__ void __launch_bounds__(256) conv_igemm_f32(const ConvArgs a) {
     int total = 0;
     for (int s = 0; s < a.nseg; ++s) total += a.seg[s].nchunks;
 
-    enter_segment(0);
-    issue_loads();
-    store_lds(0);
-    __syncthreads();
-
     const int arow = (wm * TM * 32 + (lane & 31)) * LDA + (lane >> 5) * 4;
     const int bcol = (wn * TN) * 1024 + lane * 4;
 
-    for (int it = 0; it < total; ++it) {
+    NH_ENTER_SEGMENT(0)
+    NH_ISSUE_LOADS()
+    NH_STORE_LDS(0)
+    __syncthreads();
+
+    // steady state: loads of chunk it+1 are in flight while the MFMAs of chunk it run
+    for (int it = 0; it + 1 < total; ++it) {
         const int cur = it & 1;
-        const bool more = it + 1 < total;
-        if (more) {
-            advance();
-            issue_loads();
-        }
-        const float* Ab = As + cur * A_BUF + arow;
-        const float* Bb = Bs + cur * B_BUF + bcol;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            float4 av[TM], bv[TN];
-#pragma unroll
-            for (int i = 0; i < TM; ++i) av[i] = *reinterpret_cast<const float4*>(Ab + i * 32 * LDA + q * 8);
-#pragma unroll
-            for (int j = 0; j < TN; ++j) bv[j] = *reinterpret_cast<const float4*>(Bb + j * 1024 + q * 256);
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i].x, bv[j].x, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i].y, bv[j].y, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i].z, bv[j].z, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i].w, bv[j].w, acc[i][j], 0, 0, 0);
-                }
-        }
-        if (more) store_lds(cur ^ 1);
+        NH_ADVANCE()
+        NH_ISSUE_LOADS()
+        __builtin_amdgcn_sched_barrier(0);     // keep the loads above the MFMAs that hide them
+        NH_COMPUTE(cur)
+        __builtin_amdgcn_sched_barrier(0);
+        NH_STORE_LDS(cur ^ 1)
         __syncthreads();
     }
+    NH_COMPUTE((total - 1) & 1)
+    __syncthreads();
 
-    // ---- epilogue.  C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+#undef NH_ROW
+#undef NH_LOAD_A
+#undef NH_ENTER_SEGMENT
+#undef NH_ISSUE_LOADS
+#undef NH_ADVANCE
+#undef NH_STORE_LDS
+#undef NH_COMPUTE
+
+    // ---- epilogue.  C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
+    // Per-row (clip, ho, wo, id offset) is computed once per block into LDS (the main loop's final
+    // barrier has retired every LDS read); each lane then issues all table / residual loads of a
+    // group of rows before the first use, and stores only after the last load of the group.
+    int4* rowinfo = reinterpret_cast<int4*>(smem);
+    if (tid < BM) {
+        int m = m0 + tid;
+        if (m >= a.M) m = a.M - 1;
+        const uint32_t b = fd_div((uint32_t)m, a.fdHoWo);
+        const uint32_t rem = (uint32_t)m - b * a.fdHoWo.d;
+        const uint32_t ho = fd_div(rem, a.fdWo);
+        const uint32_t wo = rem - ho * a.fdWo.d;
+        const int clip = a.img_clip ? a.img_clip[b] : 0;
+        const int ids = (int)((b * a.idH + ho * a.idsh) * a.idW + wo * a.idsw);
+        rowinfo[tid] = make_int4(clip * a.cb_stride, (int)ho * a.N, (int)wo * a.N, ids);
+    }
+    __syncthreads();
     const int ncol0 = nt * BN + wn * TN * 32 + (lane & 31);
+    // Branch-free load phase: absent tables / residuals read a[0] of a zero word with weight 0, so
+    // the compiler can issue every load of a row group before the first wait.
+    const int f_ts = a.ts ? 1 : 0, f_fs = a.fs ? 1 : 0;
+    const int f_id1 = a.id_mode == 1 ? 1 : 0, f_id2 = a.id_mode == 2 ? 1 : 0;
+    const float* __restrict__ cbp = a.cb;
+    const float* __restrict__ tsp = a.ts ? a.ts : a.zero;
+    const float* __restrict__ fsp = a.fs ? a.fs : a.zero;
+    const float* __restrict__ idp = a.id_mode ? a.id : a.zero;
+    float idw[TN];
+    int ncl[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = ncol0 + j * 32;
+        idw[j] = a.id_mode ? a.idw[n] : 0.f;
+        ncl[j] = n < a.Nreal ? n : 0;
+    }
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-            const int m = m0 + row;
-            if (m >= a.M) continue;
-            const uint32_t b = fd_div((uint32_t)m, a.fdHoWo);
-            const uint32_t rem = (uint32_t)m - b * a.fdHoWo.d;
-            const uint32_t ho = fd_div(rem, a.fdWo);
-            const uint32_t wo = rem - ho * a.fdWo.d;
-            const int clip = a.img_clip ? a.img_clip[b] : 0;
-            float idsv = 0.f;
-            if (a.id_mode == 2) idsv = a.id[((size_t)b * a.idH + ho * a.idsh) * a.idW + wo * a.idsw];
+        for (int rg = 0; rg < 4; ++rg) {              // 4 groups of 4 consecutive rows
+            float v[4][TN];
+            int mrow[4];
 #pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const int n = ncol0 + j * 32;
-                float v = acc[i][j][r] + a.cb[(size_t)clip * a.cb_stride + n];
-                if (a.ts) v += a.ts[ho * a.N + n];
-                if (a.fs) v += a.fs[wo * a.N + n];
-                if (n < a.Nreal) {
-                    if (a.aux) a.aux[(size_t)m * a.aux_ld + n] = v;
-                    if (a.id_mode == 1) v += a.idw[n] * a.id[(size_t)m * a.id_ld + n];
-                    else if (a.id_mode == 2) v += a.idw[n] * idsv;
-                    if (a.relu) v = fmaxf(v, 0.f);
-                    a.out[(size_t)m * a.ldo + n] = v;
+            for (int rr = 0; rr < 4; ++rr) {
+                const int r = rg * 4 + rr;
+                const int row = wm * TM * 32 + i * 32 + rr + 8 * rg + 4 * (lane >> 5);
+                const int4 ri = rowinfo[row];
+                int m = m0 + row;
+                mrow[rr] = m;
+                if (m >= a.M) m = a.M - 1;
+                const int64_t idrow = f_id1 ? (int64_t)m * a.id_ld : (int64_t)ri.w * f_id2;
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const int n = ncol0 + j * 32;
+                    const float c = cbp[ri.x + n];
+                    const float t = tsp[(ri.y + n) * f_ts];
+                    const float f = fsp[(ri.z + n) * f_fs];
+                    const float idv = idp[idrow + ncl[j] * f_id1];
+                    const float x = ((acc[i][j][r] + c) + t) + f;
+                    acc[i][j][r] = x;                  // pre-residual value (aux output)
+                    v[rr][j] = x + idw[j] * idv;
+                }
+            }
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                const int r = rg * 4 + rr;
+                const int m = mrow[rr];
+                if (m < a.M) {
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        const int n = ncol0 + j * 32;
+                        if (n < a.Nreal) {
+                            if (a.aux) a.aux[(size_t)m * a.aux_ld + n] = acc[i][j][r];
+                            a.out[(size_t)m * a.ldo + n] = a.relu ? fmaxf(v[rr][j], 0.f) : v[rr][j];
+                        }
+                    }
                 }
             }
         }

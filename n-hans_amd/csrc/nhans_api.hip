@@ -182,7 +182,8 @@ struct Prof {
     }
 };
 
-void fill_epilogue_defaults(ConvArgs& a) {
+void fill_epilogue_defaults(nhans_ctx* c, ConvArgs& a) {
+    a.zero = c->A("zero");
     a.img_clip = nullptr; a.ts = nullptr; a.fs = nullptr; a.id_mode = 0; a.id = nullptr; a.id_ld = 0;
     a.idw = nullptr; a.idH = a.idW = 0; a.idsh = a.idsw = 1; a.relu = 1; a.aux = nullptr; a.aux_ld = 0;
     a.cb_stride = 0;
@@ -235,7 +236,7 @@ int embed_impl(nhans_ctx* c, const float* ctx_lm, int n, float* emb_out, float* 
                 pr.done(2.0 * d.M * g.kh * g.kw * 64, 0);
             } else {
                 ConvArgs a{};
-                fill_epilogue_defaults(a);
+                fill_epilogue_defaults(c, a);
                 a.nseg = 1;
                 a.seg[0] = make_seg(x, c->A(p + ".c1.wpk"), g.hin, g.win, g.cin, g.kh, g.kw, g.sh, g.sw, true);
                 set_out_geometry(a, nc, g.hout, g.wout, g.cout, g.cout, g.cout, a1);
@@ -243,7 +244,7 @@ int embed_impl(nhans_ctx* c, const float* ctx_lm, int n, float* emb_out, float* 
                 run_conv(c, a, s);
             }
             ConvArgs a{};
-            fill_epilogue_defaults(a);
+            fill_epilogue_defaults(c, a);
             a.nseg = 1;
             a.seg[0] = make_seg(a1, c->A(p + ".c2.wpk"), g.hout, g.wout, g.cout, g.kh, g.kw, 1, 1, true);
             if (b == 0) {
@@ -328,7 +329,7 @@ float* run_stack_chunk(nhans_ctx* c, const float* logmag, const StackBufs& sb, i
             pr.done(2.0 * d.M * g.kh * g.kw * 64, 0);
         } else {
             ConvArgs a{};
-            fill_epilogue_defaults(a);
+            fill_epilogue_defaults(c, a);
             a.nseg = 1;
             a.seg[0] = make_seg(x, c->A(p + ".c1.wpk"), g.hin, g.win, g.cin, g.kh, g.kw, g.sh, g.sw, true);
             set_out_geometry(a, n, g.hout, g.wout, g.cout, g.cout, g.cout, a1);
@@ -337,7 +338,7 @@ float* run_stack_chunk(nhans_ctx* c, const float* logmag, const StackBufs& sb, i
             run_conv(c, a, s);
         }
         ConvArgs a{};
-        fill_epilogue_defaults(a);
+        fill_epilogue_defaults(c, a);
         a.nseg = 1;
         a.seg[0] = make_seg(a1, c->A(p + ".c2.wpk"), g.hout, g.wout, g.cout, g.kh, g.kw, 1, 1, true);
         a.cb = cb2; a.cb_stride = c->cond_cols; a.img_clip = clipmap;
@@ -362,7 +363,7 @@ float* run_stack_chunk(nhans_ctx* c, const float* logmag, const StackBufs& sb, i
     if (upto >= 9) {                        // last_conv [5,1] VALID + BN + ReLU  (SN/main.py:232-236)
         const BlockGeo& g = c->stack[7];
         ConvArgs a{};
-        fill_epilogue_defaults(a);
+        fill_epilogue_defaults(c, a);
         a.nseg = 1;
         a.seg[0] = make_seg(x, c->A("head.conv.wpk"), g.hout, g.wout, g.cout, g.hout, 1, 1, 1, false);
         set_out_geometry(a, n, 1, g.wout, 512, 512, 512, a1);
@@ -390,7 +391,7 @@ int mask_net_impl(nhans_ctx* c, const float* logmag, const int64_t* foff, int nc
         float* hc = run_stack_chunk(c, logmag, sb, g0, n, 9, s);
         // last_dense 13312 -> 201 (+bias) and denoised = mixed_central + out  (SN/main.py:237-242)
         ConvArgs a{};
-        fill_epilogue_defaults(a);
+        fill_epilogue_defaults(c, a);
         a.nseg = 1;
         a.seg[0] = make_seg(hc, c->A("head.dense.wpk"), 1, 1, g.wout * 512, 1, 1, 1, 1, false);
         set_out_geometry(a, n, 1, 1, 256, kBins, kBins, denoised + g0 * kBins);
@@ -530,7 +531,7 @@ int nhans_create(int model_kind, const void* blob, size_t nbytes, int device_id,
     c->cond_cols = off;
     // every array the launch sequences will dereference must be present with the right size
     std::vector<std::pair<std::string, size_t>> need = {
-        {"tw400", 800}, {"window", 400}, {"wsyn", 400},
+        {"tw400", 800}, {"window", 400}, {"wsyn", 400}, {"zero", 64},
         {"cond.w", (size_t)2 * kEmb * off}, {"cond.base", (size_t)off},
         {"head.conv.wpk", (size_t)5 * 512 * 512}, {"head.conv.cb", 512},
         {"head.dense.wpk", (size_t)26 * 512 * 256}, {"head.dense.cb", 256}, {"head.dense.idw", 256}};

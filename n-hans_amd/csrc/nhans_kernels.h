@@ -65,6 +65,7 @@ struct ConvArgs {
     int relu;
     float* aux;
     int aux_ld;
+    const float* zero;     // one readable 0.0f (stands in for absent tables / residuals)
     FastDiv fdHoWo, fdWo;
 };
 

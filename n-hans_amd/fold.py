@@ -71,6 +71,7 @@ def fold_arrays(W, kind):
         seg = win[q * spec.HOP:(q + 1) * spec.HOP] ** 2
         den[:len(seg)] += seg
     out["wsyn"] = win / np.tile(den, -(-spec.WIN // spec.HOP))[:spec.WIN]
+    out["zero"] = np.zeros(64)
 
     # --- embedding tower (SN/main.py:102-124,190-216)
     for i, g in enumerate(spec.tower_geometry()):

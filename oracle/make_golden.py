@@ -101,7 +101,7 @@ def main():
     np.savez_compressed(OUT + "/case_separator.npz", **res)
 
     print("case ragged (3 short clips, all frames)", flush=True)
-    lens = [400, 560, 16000 + 80]          # 1, 2 and 98 frames (the last one gets trimmed by 80)
+    lens = [400, 560, 16000 + 80]          # 1, 2 and 99 frames
     allres = {}
     for i, n in enumerate(lens):
         mix = O.trim_to_frames(O.normalise(synth.mixture(10 + i, n / 16000.0)))

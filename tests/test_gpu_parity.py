@@ -146,7 +146,7 @@ def test_separator_model(eng_s):
 
 
 def test_ragged_batch_edges_and_shard_invariance(eng_d):
-    """1-, 2- and 98-frame clips in one batch: window zero padding at both clip ends, no leakage
+    """1-, 2- and 99-frame clips in one batch: window zero padding at both clip ends, no leakage
     between neighbouring clips, and batch == one-by-one, bit for bit."""
     g = load_case("case_ragged")
     mixes, cas, cbs = [], [], []
@@ -154,9 +154,10 @@ def test_ragged_batch_edges_and_shard_invariance(eng_d):
         mixes.append(apply.trim_to_frames(apply.normalise(synth.mixture(10 + i, int(n) / 16000.0))))
         cas.append(apply.normalise(synth.silent()))
         cbs.append(apply.normalise(synth.noise_context(10 + i)))
-    assert [len(m) for m in mixes] == [400, 560, 16000]
+    assert [len(m) for m in mixes] == [400, 560, 16080]
     batch = eng_d.enhance(mixes, cas, cbs, want_mixed=False, taps=True)
-    foff = [0, 1, 3, 101]
+    foff = [0, 1, 3, 102]
+    assert batch["logits"].shape == (102, 201)
     for i in range(3):
         lg = batch["logits"][foff[i]:foff[i + 1]]
         # logits given the kernel's own features: allow the silent-bin feature difference
