@@ -19,6 +19,7 @@
 //   * Workgroup ids are remapped so each XCD (private L2) owns a contiguous range of pixel tiles:
 //     vertically adjacent tiles re-read the same input rows for neighbouring taps.
 #include "nhans_kernels.h"
+#include <cstdlib>
 
 namespace nhans {
 
@@ -27,7 +28,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));   // native vector: sel
 
 constexpr int BM = 128, BK = 32, LDA = 36;
 
-template <int BN, int WM, int WN>
+template <int BN, int WM, int WN, int PIPE>
 __global__ void __launch_bounds__(256) conv_igemm_f32(const ConvArgs a) {
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     constexpr int A_BUF = BM * LDA, B_BUF = BK * BN;
@@ -96,17 +97,18 @@ __global__ void __launch_bounds__(256) conv_igemm_f32(const ConvArgs a) {
 #define NH_LOAD_A(I, ROFF, RA, ROK)                                                                \
     ROK = (unsigned)(hi0[I] + kh) < (unsigned)sH && (unsigned)(wi0[I] + kw) < (unsigned)sW;       \
     RA = *reinterpret_cast<const f32x4*>(ssrc + (ROK ? ROFF + off : (int64_t)0));
-#define NH_ISSUE_LOADS()                                                                           \
+#define NH_ISSUE_LOADS_S(S)                                                                        \
     {                                                                                              \
         const int off = (kh * sW + kw) * sC + c0;                                                  \
-        NH_LOAD_A(0, roff0, ra0, rok0) NH_LOAD_A(1, roff1, ra1, rok1)                              \
-        NH_LOAD_A(2, roff2, ra2, rok2) NH_LOAD_A(3, roff3, ra3, rok3)                              \
+        NH_LOAD_A(0, roff0, ra0##S, rok0##S) NH_LOAD_A(1, roff1, ra1##S, rok1##S)                  \
+        NH_LOAD_A(2, roff2, ra2##S, rok2##S) NH_LOAD_A(3, roff3, ra3##S, rok3##S)                  \
         const f32x4* bsrc = reinterpret_cast<const f32x4*>(                                        \
             swpk + ((size_t)chunk_in_seg * (a.N / 32) + nt0) * 1024);                              \
-        rb0v = bsrc[tid];                                                                          \
-        rb1v = bsrc[256 + tid];                                                                    \
-        if constexpr (BN == 128) { rb2v = bsrc[512 + tid]; rb3v = bsrc[768 + tid]; }               \
+        rb0v##S = bsrc[tid];                                                                       \
+        rb1v##S = bsrc[256 + tid];                                                                 \
+        if constexpr (BN == 128) { rb2v##S = bsrc[512 + tid]; rb3v##S = bsrc[768 + tid]; }         \
     }
+#define NH_ISSUE_LOADS() NH_ISSUE_LOADS_S(_x)
 
 #define NH_ADVANCE()                                                                               \
     {                                                                                              \
@@ -124,23 +126,24 @@ __global__ void __launch_bounds__(256) conv_igemm_f32(const ConvArgs a) {
         }                                                                                          \
     }
 
-#define NH_STORE_LDS(BUF)                                                                          \
+#define NH_STORE_LDS_S(BUF, S)                                                                     \
     {                                                                                              \
         float* Ab_ = As + (BUF) * A_BUF;                                                           \
         float* Bb_ = Bs + (BUF) * B_BUF;                                                           \
         const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};                                                     \
         float* Ar_ = Ab_ + (tid >> 3) * LDA + col4 * 4;                                            \
-        *reinterpret_cast<f32x4*>(Ar_) = rok0 ? ra0 : z4;                                          \
-        *reinterpret_cast<f32x4*>(Ar_ + 32 * LDA) = rok1 ? ra1 : z4;                               \
-        *reinterpret_cast<f32x4*>(Ar_ + 64 * LDA) = rok2 ? ra2 : z4;                               \
-        *reinterpret_cast<f32x4*>(Ar_ + 96 * LDA) = rok3 ? ra3 : z4;                               \
-        *reinterpret_cast<f32x4*>(Bb_ + tid * 4) = rb0v;                                           \
-        *reinterpret_cast<f32x4*>(Bb_ + (256 + tid) * 4) = rb1v;                                   \
+        *reinterpret_cast<f32x4*>(Ar_) = rok0##S ? ra0##S : z4;                                    \
+        *reinterpret_cast<f32x4*>(Ar_ + 32 * LDA) = rok1##S ? ra1##S : z4;                         \
+        *reinterpret_cast<f32x4*>(Ar_ + 64 * LDA) = rok2##S ? ra2##S : z4;                         \
+        *reinterpret_cast<f32x4*>(Ar_ + 96 * LDA) = rok3##S ? ra3##S : z4;                         \
+        *reinterpret_cast<f32x4*>(Bb_ + tid * 4) = rb0v##S;                                        \
+        *reinterpret_cast<f32x4*>(Bb_ + (256 + tid) * 4) = rb1v##S;                                \
         if constexpr (BN == 128) {                                                                 \
-            *reinterpret_cast<f32x4*>(Bb_ + (512 + tid) * 4) = rb2v;                               \
-            *reinterpret_cast<f32x4*>(Bb_ + (768 + tid) * 4) = rb3v;                               \
+            *reinterpret_cast<f32x4*>(Bb_ + (512 + tid) * 4) = rb2v##S;                            \
+            *reinterpret_cast<f32x4*>(Bb_ + (768 + tid) * 4) = rb3v##S;                            \
         }                                                                                          \
     }
+#define NH_STORE_LDS(BUF) NH_STORE_LDS_S(BUF, _x)
 
 #define NH_COMPUTE(BUF)                                                                            \
     {                                                                                              \
@@ -162,8 +165,10 @@ __global__ void __launch_bounds__(256) conv_igemm_f32(const ConvArgs a) {
         }                                                                                          \
     }
 
-    f32x4 ra0, ra1, ra2, ra3, rb0v, rb1v, rb2v, rb3v;
-    bool rok0, rok1, rok2, rok3;
+    f32x4 ra0_x, ra1_x, ra2_x, ra3_x, rb0v_x, rb1v_x, rb2v_x, rb3v_x;
+    bool rok0_x, rok1_x, rok2_x, rok3_x;
+    f32x4 ra0_y, ra1_y, ra2_y, ra3_y, rb0v_y, rb1v_y, rb2v_y, rb3v_y;   // second set: PIPE == 2 only
+    bool rok0_y, rok1_y, rok2_y, rok3_y;
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -184,24 +189,94 @@ __global__ void __launch_bounds__(256) conv_igemm_f32(const ConvArgs a) {
     NH_STORE_LDS(0)
     __syncthreads();
 
-    // steady state: loads of chunk it+1 are in flight while the MFMAs of chunk it run
-    for (int it = 0; it + 1 < total; ++it) {
-        const int cur = it & 1;
-        NH_ADVANCE()
-        NH_ISSUE_LOADS()
-        __builtin_amdgcn_sched_barrier(0);     // keep the loads above the MFMAs that hide them
-        NH_COMPUTE(cur)
-        __builtin_amdgcn_sched_barrier(0);
-        NH_STORE_LDS(cur ^ 1)
+    if constexpr (PIPE == 0) {
+        // 2-stage: loads of chunk it+1 are in flight while the MFMAs of chunk it run
+        for (int it = 0; it + 1 < total; ++it) {
+            const int cur = it & 1;
+            NH_ADVANCE()
+            NH_ISSUE_LOADS()
+            __builtin_amdgcn_sched_barrier(0);     // keep the loads above the MFMAs that hide them
+            NH_COMPUTE(cur)
+            __builtin_amdgcn_sched_barrier(0);
+            NH_STORE_LDS(cur ^ 1)
+            __syncthreads();
+        }
+        NH_COMPUTE((total - 1) & 1)
+        __syncthreads();
+    } else if constexpr (PIPE == 2) {
+        // 4-stage, two register sets, loop unrolled by two, no scheduling fences: chunk it+2 is
+        // loaded at the top of iteration it, chunk it+1 goes registers -> LDS at its bottom, so every
+        // memory operation has a whole iteration of MFMAs to hide behind wherever the compiler's
+        // scheduler interleaves it.
+        if (total > 1) {
+            NH_ADVANCE()
+            NH_ISSUE_LOADS_S(_y)                    // chunk 1 -> set y
+        }
+        int it = 0;
+        for (; it + 3 < total; it += 2) {
+            NH_ADVANCE()
+            NH_ISSUE_LOADS_S(_x)                    // chunk it+2 -> set x
+            NH_COMPUTE(0)                           // chunk it (buffer 0)
+            NH_STORE_LDS_S(1, _y)                   // chunk it+1 -> buffer 1
+            __syncthreads();
+            NH_ADVANCE()
+            NH_ISSUE_LOADS_S(_y)                    // chunk it+3 -> set y
+            NH_COMPUTE(1)                           // chunk it+1
+            NH_STORE_LDS_S(0, _x)                   // chunk it+2 -> buffer 0
+            __syncthreads();
+        }
+        // tail: it is even, 1..3 chunks left; chunk it is in buffer 0, chunk it+1 (if any) in set y
+        if (it + 2 < total) {
+            NH_ADVANCE()
+            NH_ISSUE_LOADS_S(_x)                    // chunk it+2
+        }
+        NH_COMPUTE(0)
+        if (it + 1 < total) {
+            NH_STORE_LDS_S(1, _y)
+            __syncthreads();
+            NH_COMPUTE(1)
+            if (it + 2 < total) {
+                NH_STORE_LDS_S(0, _x)
+                __syncthreads();
+                NH_COMPUTE(0)
+            }
+        }
+        __syncthreads();
+    } else {
+        // 3-stage: global loads run one full chunk ahead of the LDS write that consumes them, so
+        // neither the LDS write (chunk it+1) nor the MFMAs (chunk it) ever wait on HBM/L2 latency.
+        if (total > 1) {
+            NH_ADVANCE()
+            NH_ISSUE_LOADS()                        // chunk 1 -> registers
+        }
+        int it = 0;
+        for (; it + 2 < total; ++it) {
+            const int cur = it & 1;
+            NH_STORE_LDS(cur ^ 1)                   // chunk it+1: registers -> LDS
+            NH_ADVANCE()
+            NH_ISSUE_LOADS()                        // chunk it+2 -> registers
+            __builtin_amdgcn_sched_barrier(0);
+            NH_COMPUTE(cur)
+            __syncthreads();
+        }
+        if (it + 1 < total) {
+            const int cur = it & 1;
+            NH_STORE_LDS(cur ^ 1)
+            __builtin_amdgcn_sched_barrier(0);
+            NH_COMPUTE(cur)
+            __syncthreads();
+            ++it;
+        }
+        NH_COMPUTE(it & 1)
         __syncthreads();
     }
-    NH_COMPUTE((total - 1) & 1)
-    __syncthreads();
 
 #undef NH_ROW
 #undef NH_LOAD_A
 #undef NH_ENTER_SEGMENT
 #undef NH_ISSUE_LOADS
+#undef NH_ISSUE_LOADS_S
+#undef NH_STORE_LDS_S
 #undef NH_ADVANCE
 #undef NH_STORE_LDS
 #undef NH_COMPUTE
@@ -286,25 +361,29 @@ __global__ void __launch_bounds__(256) conv_igemm_f32(const ConvArgs a) {
     }
 }
 
-template <int BN, int WM, int WN>
+template <int BN, int WM, int WN, int PIPE>
 static void launch_t(const ConvArgs& a, hipStream_t s) {
     constexpr size_t lds = (2 * BM * LDA + 2 * BK * BN) * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_f32<BN, WM, WN>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_f32<BN, WM, WN, PIPE>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
     const int mtiles = (a.M + BM - 1) / BM;
     const int grid = mtiles * (a.N / BN);
-    hipLaunchKernelGGL((conv_igemm_f32<BN, WM, WN>), dim3(grid), dim3(256), lds, s, a);
+    hipLaunchKernelGGL((conv_igemm_f32<BN, WM, WN, PIPE>), dim3(grid), dim3(256), lds, s, a);
 }
 
 double launch_conv_igemm(const ConvArgs& a, hipStream_t s) {
     double k = 0;
     for (int i = 0; i < a.nseg; ++i) k += (double)a.seg[i].nchunks * BK;
-    if (a.N % 128 == 0) launch_t<128, 2, 2>(a, s);
-    else launch_t<64, 4, 1>(a, s);
+    static const int pipe = [] { const char* e = getenv("NHANS_CONV_PIPE"); return e ? atoi(e) : 1; }();
+    if (a.N % 128 == 0) {
+        if (pipe == 2) launch_t<128, 2, 2, 2>(a, s); else if (pipe == 1) launch_t<128, 2, 2, 1>(a, s); else launch_t<128, 2, 2, 0>(a, s);
+    } else {
+        if (pipe == 2) launch_t<64, 4, 1, 2>(a, s); else if (pipe == 1) launch_t<64, 4, 1, 1>(a, s); else launch_t<64, 4, 1, 0>(a, s);
+    }
     return 2.0 * (double)a.M * k * (double)a.Nreal;
 }
 
