@@ -25,6 +25,7 @@ from nhans_amd import engine, spec, synth, weights  # noqa: E402
 from nhans_amd.apply import normalise, trim_to_frames  # noqa: E402
 
 F32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+F16_MFMA_PEAK_TFLOPS = 2500.0     # dense f16 MFMA peak; the split mode executes 3 products per MAC
 HBM_PEAK_GBS = 8000.0
 
 
@@ -38,6 +39,7 @@ def parse():
     p.add_argument("--seconds", type=float, default=10.0)
     p.add_argument("--kind", default="denoiser", choices=["denoiser", "separator"])
     p.add_argument("--frames-per-chunk", type=int, default=0)
+    p.add_argument("--precision", default="f16x3", choices=["f32", "f16x3"])
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-frames", type=int, default=32, help="frames of the CPU baseline sample")
     p.add_argument("--cpu-threads", type=int, default=0, help="0 = min(host cores, 64)")
@@ -97,7 +99,7 @@ def main():
     torch.cuda.set_device(dev)
 
     W = weights.synthetic_weights(a.kind, 7)
-    eng = engine.Engine(a.kind, W, device=local, frames_per_chunk=a.frames_per_chunk or None)
+    eng = engine.Engine(a.kind, W, device=local, frames_per_chunk=a.frames_per_chunk or None, precision=a.precision)
     mixes, ca, cb = make_batch(a.kind, rank, a.clips_per_gpu, a.seconds)
     mix_t, mix_off = eng._dev(mixes)
     ca_t, ca_off = eng._dev(ca)
@@ -137,7 +139,9 @@ def main():
         dt = float(t.item())
 
     if rank == 0:
-        conv = prof.get("conv_igemm_f32", {"ms": 0.0, "flops": 0.0, "calls": 0})
+        kname = "conv_igemm_h3" if a.precision == "f16x3" else "conv_igemm_f32"
+        peak = F16_MFMA_PEAK_TFLOPS if a.precision == "f16x3" else F32_MFMA_PEAK_TFLOPS
+        conv = prof.get(kname, {"ms": 0.0, "flops": 0.0, "calls": 0})
         tflops = conv["flops"] / (conv["ms"] * 1e-3) / 1e12 if conv["ms"] > 0 else 0.0
         stft = prof.get("stft_features", {"ms": 0.0, "bytes": 0.0})
         istft = prof.get("istft_ola", {"ms": 0.0, "bytes": 0.0})
@@ -149,16 +153,18 @@ def main():
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": 1e3 * dt / a.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": "f32" if a.precision == "f32" else "f16x3 (split hi+lo f16 operands, f32 accumulate)",
+            "data": "synthetic",
             "config": {"workload": "%d x %.0f s 16 kHz synthetic mixture(s) per GPU, %s model, STFT+embed+mask+iSTFT end-to-end%s"
                                    % (a.clips_per_gpu, a.seconds, a.kind, " + RCCL all-gather" if world > 1 else ""),
                        "clips_per_gpu": a.clips_per_gpu, "frames_per_gpu": frames, "weights": "synthetic seed 7",
                        "parallelism": "clip-sharded x%d" % world},
             "frames_per_s": world * frames * a.steps / dt,
             "x_realtime_per_gpu": audio_s * a.steps / dt,
-            "roofline": {"bound": "mfma", "kernel": "conv_igemm_f32", "achieved": tflops, "peak": F32_MFMA_PEAK_TFLOPS,
-                         "unit": "TFLOP/s", "frac": tflops / F32_MFMA_PEAK_TFLOPS, "traffic": None,
-                         "launches": conv["calls"], "kernel_ms_per_step": conv["ms"] / a.steps},
+            "roofline": {"bound": "mfma", "kernel": kname, "achieved": tflops, "peak": peak,
+                         "unit": "TFLOP/s", "frac": tflops / peak, "traffic": None,
+                         "launches": conv["calls"], "kernel_ms_per_step": conv["ms"] / a.steps,
+                         "executed_tflops": tflops * (3 if a.precision == "f16x3" else 1)},
             "hbm_kernels": {"stft_features_GBs": gbs(stft), "istft_ola_GBs": gbs(istft), "peak_GBs": HBM_PEAK_GBS},
             "kernel_ms_per_step": {k: v["ms"] / a.steps for k, v in prof.items()},
         }

@@ -68,7 +68,10 @@ void nhans_destroy(nhans_ctx* ctx);
 
 /* Options: "frames_per_chunk" (mask-net frame windows per pass, default 1024),
  *          "contexts_per_chunk" (embedding-tower images per pass, default 64),
- *          "profile" (1: time every kernel launch with hipEvents on the launch stream). */
+ *          "profile" (1: time every kernel launch with hipEvents on the launch stream),
+ *          "precision" (0: exact f32 matrix-core path, default; 1: split-f16 x3 -- every operand is
+ *           carried as hi+lo f16 and multiplied with three f16 MFMAs into an f32 accumulator;
+ *           FP32-class accuracy, activations must stay below the f16 range 65504). */
 int nhans_set_option(nhans_ctx* ctx, const char* key, int64_t value);
 
 /* Bytes of device workspace the context would hold for a batch of this shape. */

@@ -51,8 +51,37 @@ __global__ void __launch_bounds__(256) direct_conv64(const DirectArgs a) {
             acc.x = fmaxf(acc.x, 0.f); acc.y = fmaxf(acc.y, 0.f);
             acc.z = fmaxf(acc.z, 0.f); acc.w = fmaxf(acc.w, 0.f);
         }
-        *reinterpret_cast<float4*>(a.out + (size_t)m * 64 + c) = acc;
+        if (a.out_split) {
+            // split NHWC: group g = c/32 of pixel m is one 128-byte line, 32 hi halfs then 32 lo halfs
+            typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+            h4 hi, lo;
+            hi.x = (_Float16)acc.x; hi.y = (_Float16)acc.y; hi.z = (_Float16)acc.z; hi.w = (_Float16)acc.w;
+            lo.x = (_Float16)(acc.x - (float)hi.x); lo.y = (_Float16)(acc.y - (float)hi.y);
+            lo.z = (_Float16)(acc.z - (float)hi.z); lo.w = (_Float16)(acc.w - (float)hi.w);
+            _Float16* line = reinterpret_cast<_Float16*>(a.out + (size_t)m * 64) + (c >> 5) * 64 + (c & 31);
+            *reinterpret_cast<h4*>(line) = hi;
+            *reinterpret_cast<h4*>(line + 32) = lo;
+        } else {
+            *reinterpret_cast<float4*>(a.out + (size_t)m * 64 + c) = acc;
+        }
     }
+}
+
+__global__ void __launch_bounds__(256) unsplit_kernel(const float* src, int64_t total, int C, float* dst) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t m = i / C;
+        const int n = (int)(i - m * C);
+        const _Float16* p = reinterpret_cast<const _Float16*>(src + m * C) + (n >> 5) * 64 + (n & 31);
+        dst[i] = (float)p[0] + (float)p[32];
+    }
+}
+
+void launch_unsplit(const float* src, int64_t M, int C, float* dst, hipStream_t s) {
+    const int64_t total = M * C;
+    if (total <= 0) return;
+    int64_t blocks = (total + 255) / 256;
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    hipLaunchKernelGGL(unsplit_kernel, dim3((unsigned)blocks), dim3(256), 0, s, src, total, C, dst);
 }
 
 void launch_direct_conv64(const DirectArgs& a, hipStream_t s) {
@@ -110,13 +139,18 @@ void launch_gather_windows(const float* logmag, const int* f_t, const int* f_T, 
 // ---------------------------------------------------------------------------------------------
 // tf.nn.avg_pool2d over the whole map (SN/main.py:199-202).  One block per (image, 64 channels);
 // fixed summation order -> deterministic.
-__global__ void __launch_bounds__(256) avgpool_kernel(const float* x, int HW, int C, float* out) {
+__global__ void __launch_bounds__(256) avgpool_kernel(const float* x, int HW, int C, int split, float* out) {
     __shared__ float part[4][64];
     const int b = blockIdx.x, cg = blockIdx.y;
     const int c = cg * 64 + (threadIdx.x & 63), p = threadIdx.x >> 6;
     const float* base = x + (size_t)b * HW * C + c;
     float s = 0.f;
-    for (int i = p; i < HW; i += 4) s += base[(size_t)i * C];
+    if (split) {
+        const _Float16* hb = reinterpret_cast<const _Float16*>(x + (size_t)b * HW * C) + (c >> 5) * 64 + (c & 31);
+        for (int i = p; i < HW; i += 4) s += (float)hb[(size_t)i * 2 * C] + (float)hb[(size_t)i * 2 * C + 32];
+    } else {
+        for (int i = p; i < HW; i += 4) s += base[(size_t)i * C];
+    }
     part[p][threadIdx.x & 63] = s;
     __syncthreads();
     if (p == 0) {
@@ -125,9 +159,9 @@ __global__ void __launch_bounds__(256) avgpool_kernel(const float* x, int HW, in
     }
 }
 
-void launch_avgpool(const float* x, int B, int HW, int C, float* out, hipStream_t s) {
+void launch_avgpool(const float* x, int B, int HW, int C, int split, float* out, hipStream_t s) {
     if (B <= 0) return;
-    hipLaunchKernelGGL(avgpool_kernel, dim3(B, C / 64), dim3(256), 0, s, x, HW, C, out);
+    hipLaunchKernelGGL(avgpool_kernel, dim3(B, C / 64), dim3(256), 0, s, x, HW, C, split, out);
 }
 
 // ---------------------------------------------------------------------------------------------

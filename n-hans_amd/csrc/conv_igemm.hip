@@ -1,35 +1,57 @@
-// Implicit-GEMM NHWC convolution on the gfx950 f32 matrix cores, with the N-HANS block epilogue
+// Implicit-GEMM NHWC convolution on the gfx950 matrix cores, with the N-HANS block epilogue
 // (conditioning bias + position tables + residual + ReLU; BatchNorm is folded into the weights
 // and tables on the host) fused in.
 //
 // Replaces tf.nn.conv2d + bias + broadcast adds + tf.nn.batch_normalization + tf.nn.relu of
 // SN/blocks.py:38-48,104-108 and SN/main.py:102-124,161-187,232-238.
 //
+// Two arithmetic modes share the tiling, staging and epilogue:
+//   PREC 0  exact f32: v_mfma_f32_32x32x2_f32 (157 TF pipe).  Activations are f32 NHWC.
+//   PREC 1  split f16 x3 on the 2.5 PF f16 pipe: every value is carried as hi + lo with
+//           hi = f16(x), lo = f16(x - hi); a*b ~ ah*bh + ah*bl + al*bh accumulated in f32 by
+//           v_mfma_f32_32x32x16_f16 (FP32-class result: the dropped al*bl term is 2^-22 relative).
+//           Activations live in HBM already split ("split NHWC": per pixel and per group of 32
+//           channels one 128-byte line = 32 hi halfs then 32 lo halfs), written that way by the
+//           producing epilogue, so the K loop only copies bytes.  Weight columns are pre-scaled by a
+//           power of two into [32,64) so their lo parts stay normal f16 numbers; the epilogue undoes it.
+//   A 32-channel chunk of one pixel occupies the same 128 bytes in both layouts, so the staging
+//   code is identical.
+//
 // Tiling (one workgroup = 4 wavefronts of 64 lanes, 128 output pixels x BN output channels):
-//   * K is walked in chunks of 32 input channels of one filter tap.  The A chunk (128 pixels x 32
-//     channels, gathered with SAME zero padding) and the B chunk (32 x BN, pre-packed on the host
-//     in MFMA fragment order) are double-buffered in LDS; global loads for chunk i+1 are issued
-//     before the MFMAs of chunk i and written to LDS after them (one barrier per chunk).
-//   * v_mfma_f32_32x32x2_f32: lane l supplies A[row = l&31][k = l>>5] and B[k = l>>5][col = l&31].
-//     K order inside a chunk is permuted so each lane reads its operands as 16-byte vectors:
-//     MFMA (q, e) consumes k = 8q + 4(l>>5) + e, i.e. one ds_read_b128 per q per 32-row tile.
-//   * LDS A rows are padded to 36 floats: the 16 rows of a ds_read_b128 lane group then start on
-//     16 distinct 16-byte bank slots (36*i mod 64 covers all multiples of 4), so reads are
-//     conflict-free; B fragments are lane-linear.
+//   * K is walked in chunks of 32 input channels of one filter tap.  The A chunk (128 pixels x 128
+//     bytes, gathered with TF-SAME asymmetric zero padding) and the B chunk (pre-packed on the host
+//     in MFMA fragment order, 4 KB per 32 output channels) are double-buffered in LDS.
+//   * 4-stage software pipeline with two staging register sets, unrolled by two: chunk it+2 is
+//     loaded from global memory at the top of iteration it, chunk it+1 goes registers -> LDS at its
+//     bottom, chunk it is multiplied from LDS; one barrier per chunk, no memory operation is ever
+//     waited for in the iteration that issued it.
+//   * f32: lane l supplies A[row = l&31][k = l>>5], B[k = l>>5][col = l&31]; K inside a chunk is
+//     permuted (MFMA (q,e) takes k = 8q + 4(l>>5) + e) so operands are read as 16-byte vectors.
+//     f16: lane l supplies 8 consecutive k of A row l&31 / B column l&31, k-group l>>5.
+//   * LDS A rows are padded to 144 bytes: the 16 rows of a ds_read_b128 lane group start on 16
+//     distinct 16-byte bank slots (36*i mod 64 covers all multiples of 4); B is lane-linear.
 //   * Workgroup ids are remapped so each XCD (private L2) owns a contiguous range of pixel tiles:
 //     vertically adjacent tiles re-read the same input rows for neighbouring taps.
+//   * Epilogue: per-row (clip, h, w) is staged once in LDS; all table / residual loads of a row
+//     group are issued branch-free before the first use; stores follow.
 #include "nhans_kernels.h"
-#include <cstdlib>
 
 namespace nhans {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));   // native vector: selects stay in registers
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int BM = 128, BK = 32, LDA = 36;
 
-template <int BN, int WM, int WN, int PIPE>
-__global__ void __launch_bounds__(256) conv_igemm_f32(const ConvArgs a) {
+__device__ __forceinline__ float split_load(const float* base, size_t row_floats, int n) {
+    // value (hi + lo) of channel n of a split-NHWC pixel whose line starts at base + row_floats
+    const _Float16* p = reinterpret_cast<const _Float16*>(base + row_floats) + (n >> 5) * 64 + (n & 31);
+    return (float)p[0] + (float)p[32];
+}
+
+template <int BN, int WM, int WN, int PREC>
+__global__ void __launch_bounds__(256) conv_igemm(const ConvArgs a) {
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     constexpr int A_BUF = BM * LDA, B_BUF = BK * BN;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -67,7 +89,7 @@ __global__ void __launch_bounds__(256) conv_igemm_f32(const ConvArgs a) {
         }
     }
 
-    // per-segment row state (kept in scalars / constant-indexed arrays so it stays in registers)
+    // per-segment row state (scalars / constant-indexed arrays so it stays in registers)
     int64_t roff0, roff1, roff2, roff3;
     int hi0[4], wi0[4];
     int seg = 0, kh = 0, kw = 0, c0 = 0, chunk_in_seg = 0;
@@ -97,7 +119,7 @@ __global__ void __launch_bounds__(256) conv_igemm_f32(const ConvArgs a) {
 #define NH_LOAD_A(I, ROFF, RA, ROK)                                                                \
     ROK = (unsigned)(hi0[I] + kh) < (unsigned)sH && (unsigned)(wi0[I] + kw) < (unsigned)sW;       \
     RA = *reinterpret_cast<const f32x4*>(ssrc + (ROK ? ROFF + off : (int64_t)0));
-#define NH_ISSUE_LOADS_S(S)                                                                        \
+#define NH_ISSUE_LOADS(S)                                                                          \
     {                                                                                              \
         const int off = (kh * sW + kw) * sC + c0;                                                  \
         NH_LOAD_A(0, roff0, ra0##S, rok0##S) NH_LOAD_A(1, roff1, ra1##S, rok1##S)                  \
@@ -108,7 +130,6 @@ __global__ void __launch_bounds__(256) conv_igemm_f32(const ConvArgs a) {
         rb1v##S = bsrc[256 + tid];                                                                 \
         if constexpr (BN == 128) { rb2v##S = bsrc[512 + tid]; rb3v##S = bsrc[768 + tid]; }         \
     }
-#define NH_ISSUE_LOADS() NH_ISSUE_LOADS_S(_x)
 
 #define NH_ADVANCE()                                                                               \
     {                                                                                              \
@@ -126,7 +147,7 @@ __global__ void __launch_bounds__(256) conv_igemm_f32(const ConvArgs a) {
         }                                                                                          \
     }
 
-#define NH_STORE_LDS_S(BUF, S)                                                                     \
+#define NH_STORE_LDS(BUF, S)                                                                       \
     {                                                                                              \
         float* Ab_ = As + (BUF) * A_BUF;                                                           \
         float* Bb_ = Bs + (BUF) * B_BUF;                                                           \
@@ -143,9 +164,9 @@ __global__ void __launch_bounds__(256) conv_igemm_f32(const ConvArgs a) {
             *reinterpret_cast<f32x4*>(Bb_ + (768 + tid) * 4) = rb3v##S;                            \
         }                                                                                          \
     }
-#define NH_STORE_LDS(BUF) NH_STORE_LDS_S(BUF, _x)
 
-#define NH_COMPUTE(BUF)                                                                            \
+    // f32: A piece (q) of row i at float offset q*8 + (lane>>5)*4; B piece at q*256 + lane*4.
+#define NH_COMPUTE_F32(BUF)                                                                        \
     {                                                                                              \
         const float* Ab_ = As + (BUF) * A_BUF + arow;                                              \
         const float* Bb_ = Bs + (BUF) * B_BUF + bcol;                                              \
@@ -165,9 +186,37 @@ __global__ void __launch_bounds__(256) conv_igemm_f32(const ConvArgs a) {
         }                                                                                          \
     }
 
+    // f16 x3: k-step s (16 k): A hi piece of row i at float offset (2s + (lane>>5))*4, lo piece 16
+    // floats further; B pieces at ((s*2 + h)*64 + lane)*4 with h = 0 (hi) / 1 (lo).
+#define NH_COMPUTE_H3(BUF)                                                                         \
+    {                                                                                              \
+        const float* Ab_ = As + (BUF) * A_BUF + arow;                                              \
+        const float* Bb_ = Bs + (BUF) * B_BUF + bcol;                                              \
+        _Pragma("unroll") for (int s = 0; s < 2; ++s) {                                            \
+            f16x8 ah[TM], al[TM], bh[TN], bl[TN];                                                  \
+            _Pragma("unroll") for (int i = 0; i < TM; ++i) {                                       \
+                ah[i] = __builtin_bit_cast(f16x8, *reinterpret_cast<const f32x4*>(Ab_ + i * 32 * LDA + s * 8));      \
+                al[i] = __builtin_bit_cast(f16x8, *reinterpret_cast<const f32x4*>(Ab_ + i * 32 * LDA + 16 + s * 8)); \
+            }                                                                                      \
+            _Pragma("unroll") for (int j = 0; j < TN; ++j) {                                       \
+                bh[j] = __builtin_bit_cast(f16x8, *reinterpret_cast<const f32x4*>(Bb_ + j * 1024 + s * 512));        \
+                bl[j] = __builtin_bit_cast(f16x8, *reinterpret_cast<const f32x4*>(Bb_ + j * 1024 + s * 512 + 256)); \
+            }                                                                                      \
+            _Pragma("unroll") for (int i = 0; i < TM; ++i)                                         \
+                _Pragma("unroll") for (int j = 0; j < TN; ++j) {                                   \
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0); \
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0); \
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0); \
+                }                                                                                  \
+        }                                                                                          \
+    }
+
+#define NH_COMPUTE(BUF)                                                                            \
+    if constexpr (PREC == 0) NH_COMPUTE_F32(BUF) else NH_COMPUTE_H3(BUF)
+
     f32x4 ra0_x, ra1_x, ra2_x, ra3_x, rb0v_x, rb1v_x, rb2v_x, rb3v_x;
     bool rok0_x, rok1_x, rok2_x, rok3_x;
-    f32x4 ra0_y, ra1_y, ra2_y, ra3_y, rb0v_y, rb1v_y, rb2v_y, rb3v_y;   // second set: PIPE == 2 only
+    f32x4 ra0_y, ra1_y, ra2_y, ra3_y, rb0v_y, rb1v_y, rb2v_y, rb3v_y;
     bool rok0_y, rok1_y, rok2_y, rok3_y;
 
     f32x16 acc[TM][TN];
@@ -185,106 +234,56 @@ __global__ void __launch_bounds__(256) conv_igemm_f32(const ConvArgs a) {
     const int bcol = (wn * TN) * 1024 + lane * 4;
 
     NH_ENTER_SEGMENT(0)
-    NH_ISSUE_LOADS()
-    NH_STORE_LDS(0)
+    NH_ISSUE_LOADS(_x)
+    NH_STORE_LDS(0, _x)
+    if (total > 1) {
+        NH_ADVANCE()
+        NH_ISSUE_LOADS(_y)                          // chunk 1 -> set y
+    }
     __syncthreads();
 
-    if constexpr (PIPE == 0) {
-        // 2-stage: loads of chunk it+1 are in flight while the MFMAs of chunk it run
-        for (int it = 0; it + 1 < total; ++it) {
-            const int cur = it & 1;
-            NH_ADVANCE()
-            NH_ISSUE_LOADS()
-            __builtin_amdgcn_sched_barrier(0);     // keep the loads above the MFMAs that hide them
-            NH_COMPUTE(cur)
-            __builtin_amdgcn_sched_barrier(0);
-            NH_STORE_LDS(cur ^ 1)
-            __syncthreads();
-        }
-        NH_COMPUTE((total - 1) & 1)
+    int it = 0;
+    for (; it + 3 < total; it += 2) {
+        NH_ADVANCE()
+        NH_ISSUE_LOADS(_x)                          // chunk it+2 -> set x
+        NH_COMPUTE(0)                               // chunk it (buffer 0)
+        NH_STORE_LDS(1, _y)                         // chunk it+1 -> buffer 1
         __syncthreads();
-    } else if constexpr (PIPE == 2) {
-        // 4-stage, two register sets, loop unrolled by two, no scheduling fences: chunk it+2 is
-        // loaded at the top of iteration it, chunk it+1 goes registers -> LDS at its bottom, so every
-        // memory operation has a whole iteration of MFMAs to hide behind wherever the compiler's
-        // scheduler interleaves it.
-        if (total > 1) {
-            NH_ADVANCE()
-            NH_ISSUE_LOADS_S(_y)                    // chunk 1 -> set y
-        }
-        int it = 0;
-        for (; it + 3 < total; it += 2) {
-            NH_ADVANCE()
-            NH_ISSUE_LOADS_S(_x)                    // chunk it+2 -> set x
-            NH_COMPUTE(0)                           // chunk it (buffer 0)
-            NH_STORE_LDS_S(1, _y)                   // chunk it+1 -> buffer 1
-            __syncthreads();
-            NH_ADVANCE()
-            NH_ISSUE_LOADS_S(_y)                    // chunk it+3 -> set y
-            NH_COMPUTE(1)                           // chunk it+1
-            NH_STORE_LDS_S(0, _x)                   // chunk it+2 -> buffer 0
-            __syncthreads();
-        }
-        // tail: it is even, 1..3 chunks left; chunk it is in buffer 0, chunk it+1 (if any) in set y
-        if (it + 2 < total) {
-            NH_ADVANCE()
-            NH_ISSUE_LOADS_S(_x)                    // chunk it+2
-        }
-        NH_COMPUTE(0)
-        if (it + 1 < total) {
-            NH_STORE_LDS_S(1, _y)
-            __syncthreads();
-            NH_COMPUTE(1)
-            if (it + 2 < total) {
-                NH_STORE_LDS_S(0, _x)
-                __syncthreads();
-                NH_COMPUTE(0)
-            }
-        }
-        __syncthreads();
-    } else {
-        // 3-stage: global loads run one full chunk ahead of the LDS write that consumes them, so
-        // neither the LDS write (chunk it+1) nor the MFMAs (chunk it) ever wait on HBM/L2 latency.
-        if (total > 1) {
-            NH_ADVANCE()
-            NH_ISSUE_LOADS()                        // chunk 1 -> registers
-        }
-        int it = 0;
-        for (; it + 2 < total; ++it) {
-            const int cur = it & 1;
-            NH_STORE_LDS(cur ^ 1)                   // chunk it+1: registers -> LDS
-            NH_ADVANCE()
-            NH_ISSUE_LOADS()                        // chunk it+2 -> registers
-            __builtin_amdgcn_sched_barrier(0);
-            NH_COMPUTE(cur)
-            __syncthreads();
-        }
-        if (it + 1 < total) {
-            const int cur = it & 1;
-            NH_STORE_LDS(cur ^ 1)
-            __builtin_amdgcn_sched_barrier(0);
-            NH_COMPUTE(cur)
-            __syncthreads();
-            ++it;
-        }
-        NH_COMPUTE(it & 1)
+        NH_ADVANCE()
+        NH_ISSUE_LOADS(_y)                          // chunk it+3 -> set y
+        NH_COMPUTE(1)                               // chunk it+1
+        NH_STORE_LDS(0, _x)                         // chunk it+2 -> buffer 0
         __syncthreads();
     }
+    // tail: it is even, 1..3 chunks left; chunk it is in buffer 0, chunk it+1 (if any) in set y
+    if (it + 2 < total) {
+        NH_ADVANCE()
+        NH_ISSUE_LOADS(_x)                          // chunk it+2
+    }
+    NH_COMPUTE(0)
+    if (it + 1 < total) {
+        NH_STORE_LDS(1, _y)
+        __syncthreads();
+        NH_COMPUTE(1)
+        if (it + 2 < total) {
+            NH_STORE_LDS(0, _x)
+            __syncthreads();
+            NH_COMPUTE(0)
+        }
+    }
+    __syncthreads();
 
 #undef NH_ROW
 #undef NH_LOAD_A
 #undef NH_ENTER_SEGMENT
 #undef NH_ISSUE_LOADS
-#undef NH_ISSUE_LOADS_S
-#undef NH_STORE_LDS_S
 #undef NH_ADVANCE
 #undef NH_STORE_LDS
+#undef NH_COMPUTE_F32
+#undef NH_COMPUTE_H3
 #undef NH_COMPUTE
 
     // ---- epilogue.  C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
-    // Per-row (clip, ho, wo, id offset) is computed once per block into LDS (the main loop's final
-    // barrier has retired every LDS read); each lane then issues all table / residual loads of a
-    // group of rows before the first use, and stores only after the last load of the group.
     int4* rowinfo = reinterpret_cast<int4*>(smem);
     if (tid < BM) {
         int m = m0 + tid;
@@ -299,20 +298,22 @@ __global__ void __launch_bounds__(256) conv_igemm_f32(const ConvArgs a) {
     }
     __syncthreads();
     const int ncol0 = nt * BN + wn * TN * 32 + (lane & 31);
-    // Branch-free load phase: absent tables / residuals read a[0] of a zero word with weight 0, so
-    // the compiler can issue every load of a row group before the first wait.
+    // Branch-free load phase: absent tables / residuals read a zero word with weight 0, so the
+    // compiler can issue every load of a row group before the first wait.
     const int f_ts = a.ts ? 1 : 0, f_fs = a.fs ? 1 : 0;
     const int f_id1 = a.id_mode == 1 ? 1 : 0, f_id2 = a.id_mode == 2 ? 1 : 0;
+    const bool id_split = a.id_mode == 1 && a.id_split;
     const float* __restrict__ cbp = a.cb;
     const float* __restrict__ tsp = a.ts ? a.ts : a.zero;
     const float* __restrict__ fsp = a.fs ? a.fs : a.zero;
-    const float* __restrict__ idp = a.id_mode ? a.id : a.zero;
-    float idw[TN];
+    const float* __restrict__ idp = (a.id_mode && !id_split) ? a.id : a.zero;
+    float idw[TN], wsc[TN];
     int ncl[TN];
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int n = ncol0 + j * 32;
         idw[j] = a.id_mode ? a.idw[n] : 0.f;
+        wsc[j] = PREC == 1 ? a.ws[n] : 1.f;
         ncl[j] = n < a.Nreal ? n : 0;
     }
 #pragma unroll
@@ -336,8 +337,10 @@ __global__ void __launch_bounds__(256) conv_igemm_f32(const ConvArgs a) {
                     const float c = cbp[ri.x + n];
                     const float t = tsp[(ri.y + n) * f_ts];
                     const float f = fsp[(ri.z + n) * f_fs];
-                    const float idv = idp[idrow + ncl[j] * f_id1];
-                    const float x = ((acc[i][j][r] + c) + t) + f;
+                    float idv;
+                    if (id_split) idv = split_load(a.id, (size_t)m * a.id_ld, n);
+                    else idv = idp[idrow + ncl[j] * f_id1];
+                    const float x = ((acc[i][j][r] * wsc[j] + c) + t) + f;
                     acc[i][j][r] = x;                  // pre-residual value (aux output)
                     v[rr][j] = x + idw[j] * idv;
                 }
@@ -346,14 +349,29 @@ __global__ void __launch_bounds__(256) conv_igemm_f32(const ConvArgs a) {
             for (int rr = 0; rr < 4; ++rr) {
                 const int r = rg * 4 + rr;
                 const int m = mrow[rr];
-                if (m < a.M) {
 #pragma unroll
-                    for (int j = 0; j < TN; ++j) {
-                        const int n = ncol0 + j * 32;
-                        if (n < a.Nreal) {
-                            if (a.aux) a.aux[(size_t)m * a.aux_ld + n] = acc[i][j][r];
-                            a.out[(size_t)m * a.ldo + n] = a.relu ? fmaxf(v[rr][j], 0.f) : v[rr][j];
+                for (int j = 0; j < TN; ++j) {
+                    const int n = ncol0 + j * 32;
+                    const float y = a.relu ? fmaxf(v[rr][j], 0.f) : v[rr][j];
+                    if (a.out_split) {
+                        // split NHWC: lanes pair up so that each lane stores one 32-bit word:
+                        // even lanes the two hi halfs of channels (n, n+1), odd lanes the two lo halfs
+                        const float yc = fminf(fmaxf(y, -65504.f), 65504.f);   // stay finite in f16
+                        const _Float16 h = (_Float16)yc;
+                        const _Float16 l = (_Float16)(yc - (float)h);
+                        const uint32_t w =(uint32_t)__builtin_bit_cast(uint16_t, h) |
+                                           ((uint32_t)__builtin_bit_cast(uint16_t, l) << 16);
+                        const uint32_t o = (uint32_t)__shfl_xor((int)w, 1);
+                        const bool odd = lane & 1;
+                        const uint32_t word = odd ? ((o >> 16) | (w & 0xffff0000u)) : ((w & 0xffffu) | (o << 16));
+                        if (m < a.M) {
+                            uint32_t* dst = reinterpret_cast<uint32_t*>(a.out) + (size_t)m * a.ldo + (n >> 5) * 32 +
+                                            (odd ? 16 : 0) + ((n & 31) >> 1);
+                            *dst = word;
                         }
+                    } else if (m < a.M && n < a.Nreal) {
+                        if (a.aux) a.aux[(size_t)m * a.aux_ld + n] = acc[i][j][r];
+                        a.out[(size_t)m * a.ldo + n] = y;
                     }
                 }
             }
@@ -361,28 +379,27 @@ __global__ void __launch_bounds__(256) conv_igemm_f32(const ConvArgs a) {
     }
 }
 
-template <int BN, int WM, int WN, int PIPE>
+template <int BN, int WM, int WN, int PREC>
 static void launch_t(const ConvArgs& a, hipStream_t s) {
     constexpr size_t lds = (2 * BM * LDA + 2 * BK * BN) * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_f32<BN, WM, WN, PIPE>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm<BN, WM, WN, PREC>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
     const int mtiles = (a.M + BM - 1) / BM;
     const int grid = mtiles * (a.N / BN);
-    hipLaunchKernelGGL((conv_igemm_f32<BN, WM, WN, PIPE>), dim3(grid), dim3(256), lds, s, a);
+    hipLaunchKernelGGL((conv_igemm<BN, WM, WN, PREC>), dim3(grid), dim3(256), lds, s, a);
 }
 
 double launch_conv_igemm(const ConvArgs& a, hipStream_t s) {
     double k = 0;
     for (int i = 0; i < a.nseg; ++i) k += (double)a.seg[i].nchunks * BK;
-    static const int pipe = [] { const char* e = getenv("NHANS_CONV_PIPE"); return e ? atoi(e) : 1; }();
-    if (a.N % 128 == 0) {
-        if (pipe == 2) launch_t<128, 2, 2, 2>(a, s); else if (pipe == 1) launch_t<128, 2, 2, 1>(a, s); else launch_t<128, 2, 2, 0>(a, s);
+    if (a.prec == 1) {
+        if (a.N % 128 == 0) launch_t<128, 2, 2, 1>(a, s); else launch_t<64, 4, 1, 1>(a, s);
     } else {
-        if (pipe == 2) launch_t<64, 4, 1, 2>(a, s); else if (pipe == 1) launch_t<64, 4, 1, 1>(a, s); else launch_t<64, 4, 1, 0>(a, s);
+        if (a.N % 128 == 0) launch_t<128, 2, 2, 0>(a, s); else launch_t<64, 4, 1, 0>(a, s);
     }
     return 2.0 * (double)a.M * k * (double)a.Nreal;
 }

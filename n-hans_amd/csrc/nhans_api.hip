@@ -108,10 +108,15 @@ struct nhans_ctx {
     std::map<std::string, ProfEntry> prof;
     std::vector<hipEvent_t> event_pool;
 
+    int prec = 0;           // 0: f32 MFMA, 1: split-f16 x3 MFMA (activations in split NHWC)
+
     const float* A(const std::string& n) const {
         auto it = arr.find(n);
         return it == arr.end() ? nullptr : it->second;
     }
+    // packed conv weights / per-channel unscale vector of the active precision
+    const float* WP(const std::string& n) const { return A(prec ? n + "_h" : n); }
+    const float* WS(const std::string& conv) const { return prec ? A(conv + ".ws") : nullptr; }
 };
 
 namespace {
@@ -187,6 +192,7 @@ void fill_epilogue_defaults(nhans_ctx* c, ConvArgs& a) {
     a.img_clip = nullptr; a.ts = nullptr; a.fs = nullptr; a.id_mode = 0; a.id = nullptr; a.id_ld = 0;
     a.idw = nullptr; a.idH = a.idW = 0; a.idsh = a.idsw = 1; a.relu = 1; a.aux = nullptr; a.aux_ld = 0;
     a.cb_stride = 0;
+    a.prec = c->prec; a.out_split = c->prec; a.id_split = 0; a.ws = nullptr;
 }
 
 ConvSeg make_seg(const float* src, const float* wpk, int H, int W, int C, int KH, int KW, int sh, int sw,
@@ -207,7 +213,7 @@ void set_out_geometry(ConvArgs& a, int B, int Ho, int Wo, int N, int Nreal, int 
 }
 
 void run_conv(nhans_ctx* c, const ConvArgs& a, hipStream_t s) {
-    Prof p(c, s, "conv_igemm_f32");
+    Prof p(c, s, c->prec ? "conv_igemm_h3" : "conv_igemm_f32");
     double fl = launch_conv_igemm(a, s);
     p.done(fl, 0);
 }
@@ -231,6 +237,7 @@ int embed_impl(nhans_ctx* c, const float* ctx_lm, int n, float* emb_out, float* 
                 d.Ho = g.hout; d.Wo = g.wout; d.M = nc * g.hout * g.wout; d.out = a1;
                 d.cb = c->A(p + ".c1.cb"); d.cb_stride = 0; d.img_clip = nullptr; d.ts = nullptr; d.fs = nullptr;
                 d.relu = 1; d.fdHoWo = make_fastdiv(g.hout * g.wout); d.fdWo = make_fastdiv(g.wout);
+                d.out_split = c->prec;
                 Prof pr(c, s, "direct_conv64");
                 launch_direct_conv64(d, s);
                 pr.done(2.0 * d.M * g.kh * g.kw * 64, 0);
@@ -238,30 +245,32 @@ int embed_impl(nhans_ctx* c, const float* ctx_lm, int n, float* emb_out, float* 
                 ConvArgs a{};
                 fill_epilogue_defaults(c, a);
                 a.nseg = 1;
-                a.seg[0] = make_seg(x, c->A(p + ".c1.wpk"), g.hin, g.win, g.cin, g.kh, g.kw, g.sh, g.sw, true);
+                a.seg[0] = make_seg(x, c->WP(p + ".c1.wpk"), g.hin, g.win, g.cin, g.kh, g.kw, g.sh, g.sw, true);
                 set_out_geometry(a, nc, g.hout, g.wout, g.cout, g.cout, g.cout, a1);
                 a.cb = c->A(p + ".c1.cb");
+                a.ws = c->WS(p + ".c1");
                 run_conv(c, a, s);
             }
             ConvArgs a{};
             fill_epilogue_defaults(c, a);
             a.nseg = 1;
-            a.seg[0] = make_seg(a1, c->A(p + ".c2.wpk"), g.hout, g.wout, g.cout, g.kh, g.kw, 1, 1, true);
+            a.seg[0] = make_seg(a1, c->WP(p + ".c2.wpk"), g.hout, g.wout, g.cout, g.kh, g.kw, 1, 1, true);
             if (b == 0) {
                 a.id_mode = 2; a.id = img; a.idH = g.hin; a.idW = g.win; a.idsh = g.sh; a.idsw = g.sw;
                 a.idw = c->A(p + ".c2.idw");
             } else {
                 a.nseg = 2;
-                a.seg[1] = make_seg(x, c->A(p + ".c2.wpk_t"), g.hin, g.win, g.cin, 1, 1, g.sh, g.sw, false);
+                a.seg[1] = make_seg(x, c->WP(p + ".c2.wpk_t"), g.hin, g.win, g.cin, 1, 1, g.sh, g.sw, false);
             }
             set_out_geometry(a, nc, g.hout, g.wout, g.cout, g.cout, g.cout, y);
             a.cb = c->A(p + ".c2.cb");
+            a.ws = c->WS(p + ".c2");
             run_conv(c, a, s);
             std::swap(x, y);
         }
         const BlockGeo& g = T[3];
         Prof pr(c, s, "avgpool");
-        launch_avgpool(x, nc, g.hout * g.wout, g.cout, emb_out + (size_t)i0 * kEmb, s);
+        launch_avgpool(x, nc, g.hout * g.wout, g.cout, c->prec, emb_out + (size_t)i0 * kEmb, s);
         pr.done(0, (double)nc * g.hout * g.wout * g.cout * 4);
     }
     return NHANS_OK;
@@ -322,7 +331,7 @@ float* run_stack_chunk(nhans_ctx* c, const float* logmag, const StackBufs& sb, i
             int o; same_pad(g.hin, g.kh, 1, &o, &d.pt); same_pad(g.win, g.kw, 1, &o, &d.pl);
             d.Ho = g.hout; d.Wo = g.wout; d.M = n * g.hout * g.wout; d.out = a1;
             d.cb = cb1; d.cb_stride = c->cond_cols; d.img_clip = clipmap;
-            d.ts = c->A(p + ".c1.ts"); d.fs = c->A(p + ".c1.fs"); d.relu = 1;
+            d.ts = c->A(p + ".c1.ts"); d.fs = c->A(p + ".c1.fs"); d.relu = 1; d.out_split = c->prec;
             d.fdHoWo = make_fastdiv(g.hout * g.wout); d.fdWo = make_fastdiv(g.wout);
             Prof pr(c, s, "direct_conv64");
             launch_direct_conv64(d, s);
@@ -331,29 +340,31 @@ float* run_stack_chunk(nhans_ctx* c, const float* logmag, const StackBufs& sb, i
             ConvArgs a{};
             fill_epilogue_defaults(c, a);
             a.nseg = 1;
-            a.seg[0] = make_seg(x, c->A(p + ".c1.wpk"), g.hin, g.win, g.cin, g.kh, g.kw, g.sh, g.sw, true);
+            a.seg[0] = make_seg(x, c->WP(p + ".c1.wpk"), g.hin, g.win, g.cin, g.kh, g.kw, g.sh, g.sw, true);
             set_out_geometry(a, n, g.hout, g.wout, g.cout, g.cout, g.cout, a1);
             a.cb = cb1; a.cb_stride = c->cond_cols; a.img_clip = clipmap;
             a.ts = c->A(p + ".c1.ts"); a.fs = c->A(p + ".c1.fs");
+            a.ws = c->WS(p + ".c1");
             run_conv(c, a, s);
         }
         ConvArgs a{};
         fill_epilogue_defaults(c, a);
         a.nseg = 1;
-        a.seg[0] = make_seg(a1, c->A(p + ".c2.wpk"), g.hout, g.wout, g.cout, g.kh, g.kw, 1, 1, true);
+        a.seg[0] = make_seg(a1, c->WP(p + ".c2.wpk"), g.hout, g.wout, g.cout, g.kh, g.kw, 1, 1, true);
         a.cb = cb2; a.cb_stride = c->cond_cols; a.img_clip = clipmap;
         a.ts = c->A(p + ".c2.ts"); a.fs = c->A(p + ".c2.fs");
         a.idw = c->A(p + ".c2.idw");
+        a.ws = c->WS(p + ".c2");
         float* out;
         if (b == 0) {                       // 1 -> 64 transform on the window image itself
             a.id_mode = 2; a.id = sb.xw; a.idH = g.hin; a.idW = g.win; a.idsh = 1; a.idsw = 1;
             out = x;
         } else if (g.cin == g.cout) {       // identity shortcut, written in place over the block input
-            a.id_mode = 1; a.id = x; a.id_ld = g.cout;
+            a.id_mode = 1; a.id = x; a.id_ld = g.cout; a.id_split = c->prec;
             out = x;
         } else {                            // 1x1 strided transform as extra K columns
             a.nseg = 2;
-            a.seg[1] = make_seg(x, c->A(p + ".c2.wpk_t"), g.hin, g.win, g.cin, 1, 1, g.sh, g.sw, false);
+            a.seg[1] = make_seg(x, c->WP(p + ".c2.wpk_t"), g.hin, g.win, g.cin, 1, 1, g.sh, g.sw, false);
             out = y;
         }
         set_out_geometry(a, n, g.hout, g.wout, g.cout, g.cout, g.cout, out);
@@ -365,9 +376,10 @@ float* run_stack_chunk(nhans_ctx* c, const float* logmag, const StackBufs& sb, i
         ConvArgs a{};
         fill_epilogue_defaults(c, a);
         a.nseg = 1;
-        a.seg[0] = make_seg(x, c->A("head.conv.wpk"), g.hout, g.wout, g.cout, g.hout, 1, 1, 1, false);
+        a.seg[0] = make_seg(x, c->WP("head.conv.wpk"), g.hout, g.wout, g.cout, g.hout, 1, 1, 1, false);
         set_out_geometry(a, n, 1, g.wout, 512, 512, 512, a1);
         a.cb = c->A("head.conv.cb");
+        a.ws = c->WS("head.conv");
         run_conv(c, a, s);
         return a1;
     }
@@ -393,9 +405,11 @@ int mask_net_impl(nhans_ctx* c, const float* logmag, const int64_t* foff, int nc
         ConvArgs a{};
         fill_epilogue_defaults(c, a);
         a.nseg = 1;
-        a.seg[0] = make_seg(hc, c->A("head.dense.wpk"), 1, 1, g.wout * 512, 1, 1, 1, 1, false);
+        a.seg[0] = make_seg(hc, c->WP("head.dense.wpk"), 1, 1, g.wout * 512, 1, 1, 1, 1, false);
         set_out_geometry(a, n, 1, 1, 256, kBins, kBins, denoised + g0 * kBins);
         a.cb = c->A("head.dense.cb");
+        a.ws = c->WS("head.dense");
+        a.out_split = 0;
         a.relu = 0;
         a.id_mode = 1; a.id = logmag + g0 * kBins; a.id_ld = kBins; a.idw = c->A("head.dense.idw");
         if (logits) { a.aux = logits + g0 * kBins; a.aux_ld = kBins; }
@@ -589,6 +603,12 @@ int nhans_set_option(nhans_ctx* c, const char* key, int64_t value) {
     if (k == "frames_per_chunk") { if (value < 1) return fail(NHANS_EINVAL, "frames_per_chunk < 1"); c->frames_per_chunk = value; }
     else if (k == "contexts_per_chunk") { if (value < 1) return fail(NHANS_EINVAL, "contexts_per_chunk < 1"); c->contexts_per_chunk = (int)value; }
     else if (k == "profile") c->profile = value != 0;
+    else if (k == "precision") {
+        if (value != 0 && value != 1) return fail(NHANS_EINVAL, "precision must be 0 (f32) or 1 (f16x3)");
+        if (value == 1 && !c->A("head.dense.wpk_h"))
+            return fail(NHANS_EINVAL, "the folded blob carries no split-f16 weights");
+        c->prec = (int)value;
+    }
     else return fail(NHANS_EINVAL, "unknown option " + k);
     return NHANS_OK;
 }
@@ -657,7 +677,9 @@ int nhans_debug_block_output(nhans_ctx* c, const float* logmag, const int64_t* f
     size_t per;
     if (block == 8) per = (size_t)26 * 512;
     else per = (size_t)c->stack[block].hout * c->stack[block].wout * c->stack[block].cout;
-    HIP_TRY(hipMemcpyAsync(out, res, per * nframes * 4, hipMemcpyDeviceToDevice, s));
+    if (c->prec) launch_unsplit(res, (int64_t)nframes * (int64_t)(per / (block == 8 ? 512 : c->stack[block].cout)),
+                                block == 8 ? 512 : c->stack[block].cout, out, s);
+    else HIP_TRY(hipMemcpyAsync(out, res, per * nframes * 4, hipMemcpyDeviceToDevice, s));
     return NHANS_OK;
 }
 

@@ -66,6 +66,10 @@ struct ConvArgs {
     float* aux;
     int aux_ld;
     const float* zero;     // one readable 0.0f (stands in for absent tables / residuals)
+    int prec;              // 0: f32 MFMA on f32 NHWC; 1: split-f16 x3 MFMA on split NHWC inputs
+    int out_split;         // write `out` as split NHWC (ldo = N words per pixel) instead of f32
+    int id_split;          // id_mode 1 tensor is split NHWC
+    const float* ws;       // prec 1: per-channel power-of-two that undoes the weight pre-scaling
     FastDiv fdHoWo, fdWo;
 };
 
@@ -86,9 +90,12 @@ struct DirectArgs {     // convolution of a 1-channel image into 64 channels, sa
     const float* ts;    // [Ho,64] nullable
     const float* fs;    // [Wo,64] nullable
     int relu;
+    int out_split;      // write split NHWC (hi/lo f16) instead of f32
     FastDiv fdHoWo, fdWo;
 };
 void launch_direct_conv64(const DirectArgs& a, hipStream_t s);
+// split NHWC [M, C] -> f32 [M, C]
+void launch_unsplit(const float* src, int64_t M, int C, float* dst, hipStream_t s);
 
 // frame index: for global frame g -> clip, t within clip, T of clip
 void launch_frame_index(const int64_t* frame_offsets_dev, int nclips, int64_t total, int* f_clip,
@@ -97,7 +104,7 @@ void launch_frame_index(const int64_t* frame_offsets_dev, int nclips, int64_t to
 void launch_gather_windows(const float* logmag, const int* f_t, const int* f_T, int64_t g0, int n,
                            float* xw, hipStream_t s);
 // mean over HW positions: x [B, HW, C] -> out [B, C]
-void launch_avgpool(const float* x, int B, int HW, int C, float* out, hipStream_t s);
+void launch_avgpool(const float* x, int B, int HW, int C, int split, float* out, hipStream_t s);
 // cb[clip, n] = base[n] + sum_k ea[clip,k]*Wc[k, n] + sum_k eb[clip,k]*Wc[512+k, n]
 void launch_cond(const float* ea, const float* eb, int nclips, const float* Wc, const float* base,
                  int ncols, float* cb, hipStream_t s);

@@ -1,6 +1,7 @@
 """Device-side engine: owns one libnhans_hip context and moves ragged clip batches through it.
 PyTorch is used only for device memory and streams; all arithmetic runs in the HIP library."""
 import ctypes
+import os
 
 import numpy as np
 import torch
@@ -20,7 +21,10 @@ class Engine:
     the seeded synthetic weights.  Conditioning order everywhere is (a, b) = resnet_block argument
     order: denoiser (pos, neg); separator (noise = --neg, clean = --pos)."""
 
-    def __init__(self, kind=spec.DENOISER, weights=None, device=0, seed=7, frames_per_chunk=None):
+    PRECISIONS = {"f32": 0, "f16x3": 1}
+
+    def __init__(self, kind=spec.DENOISER, weights=None, device=0, seed=7, frames_per_chunk=None,
+                 precision=None):
         if not torch.cuda.is_available():
             raise hip.NhansError("no HIP device visible: the N-HANS hot path has no CPU fallback")
         self.lib = hip.load()
@@ -35,6 +39,15 @@ class Engine:
         self.handle = handle
         if frames_per_chunk:
             self.set_option("frames_per_chunk", frames_per_chunk)
+        self.set_precision(precision)
+
+    def set_precision(self, precision):
+        """'f32': exact f32 matrix-core path.  'f16x3': split-f16 (hi+lo, three products) on the f16
+        matrix cores -- FP32-class accuracy, needs |activations| < 65504."""
+        if precision is None:
+            precision = os.environ.get("NHANS_PRECISION", "f16x3")
+        self.set_option("precision", self.PRECISIONS[precision])
+        self.precision = precision
 
     def close(self):
         if getattr(self, "handle", None):

@@ -55,10 +55,58 @@ def pack_igemm(wkn, npad=None):
     return np.ascontiguousarray(a).reshape(-1).astype(np.float32)
 
 
-def fold_arrays(W, kind):
-    """-> dict name -> float32 1-D array (see nhans_api.hip for the consumer)."""
+def col_scale(*mats):
+    """Power-of-two per output column that brings max|w| over all given [K_i, N] matrices into
+    [32, 64): the f16 `lo` parts of the scaled weights are then normal numbers (no subnormal
+    precision loss); the kernel epilogue multiplies the accumulator by 1/scale (exact)."""
+    cmax = np.max(np.stack([np.abs(m).max(axis=0) for m in mats]), axis=0)
+    e = np.floor(np.log2(np.where(cmax > 0, cmax, 1.0)))
+    return np.where(cmax > 0, 2.0 ** (5 - e), 1.0)
+
+
+def pack_igemm_h3(wkn, scale, npad=None):
+    """Split-f16 packing for conv_igemm PREC 1: w*scale = hi + lo (both f16), laid out
+    [K/32][Npad/32][s=2][h=2][64 lanes][8 halfs]; lane l, element e of k-step s holds
+    k = 32c + 16s + 8(l>>5) + e, column 32t + (l&31).  Returned as a float32 view of the half bits."""
+    k, n = wkn.shape
+    assert k % 32 == 0, k
+    npad = n if npad is None else npad
+    assert npad % 32 == 0 and npad >= n
+    wp = np.zeros((k, npad), dtype=F64)
+    wp[:, :n] = wkn * scale[None, :n]
+    hi = wp.astype(np.float16)
+    lo = (wp - hi.astype(F64)).astype(np.float16)
+    assert np.isfinite(hi).all()
+    parts = []
+    for a in (hi, lo):
+        a = a.reshape(k // 32, 2, 2, 8, npad // 32, 32)     # chunk, s, g8, e, nt, col
+        parts.append(a.transpose(0, 4, 1, 2, 5, 3))          # chunk, nt, s, g8, col, e
+    p = np.stack(parts, axis=3)                               # chunk, nt, s, h, g8, col, e
+    return np.ascontiguousarray(p).reshape(-1).view(np.float32)
+
+
+def _pad(v, npad):
+    o = np.ones(npad, dtype=F64)
+    o[:len(v)] = v
+    return o
+
+
+def fold_arrays(W, kind, split_f16=True):
+    """-> dict name -> float32 1-D array (see nhans_api.hip for the consumer).  With split_f16 the
+    blob also carries every packed conv weight in split-f16 form (`*_h`) and the per-channel
+    unscale vectors (`<conv>.ws`) for the f16x3 mode."""
     out = {}
     w64 = lambda n: W[n].astype(F64)
+
+    def emit(conv, mats, npad=None):
+        """mats: [(array name, [K,N] matrix)] sharing one accumulator -> f32 pack (+ split pack)."""
+        for name, m in mats:
+            out[name] = pack_igemm(m, npad)
+        if split_f16:
+            sc = col_scale(*[m for _, m in mats])
+            for name, m in mats:
+                out[name + "_h"] = pack_igemm_h3(m, sc, npad)
+            out[conv + ".ws"] = _pad(1.0 / sc, npad or len(sc))
 
     # --- transform constants (tf.signal.stft / inverse_stft_window_fn)
     j = np.arange(spec.WIN, dtype=F64)
@@ -81,15 +129,16 @@ def fold_arrays(W, kind):
         if g["cin"] == 1:
             out[p + ".c1.w"] = w1.reshape(-1)
         else:
-            out[p + ".c1.wpk"] = pack_igemm(w1)
+            emit(p + ".c1", [(p + ".c1.wpk", w1)])
         out[p + ".c1.cb"] = h1
         sa, ha = _bn(W, s + "_addition")
-        out[p + ".c2.wpk"] = pack_igemm(w64(s + "_conv2/w").reshape(-1, g["cout"]) * sa)
+        w2 = w64(s + "_conv2/w").reshape(-1, g["cout"]) * sa
         wt = w64(s + "_transform/w").reshape(g["cin"], g["cout"]) * sa
         if g["cin"] == 1:
             out[p + ".c2.idw"] = wt.reshape(-1)
+            emit(p + ".c2", [(p + ".c2.wpk", w2)])
         else:
-            out[p + ".c2.wpk_t"] = pack_igemm(wt)
+            emit(p + ".c2", [(p + ".c2.wpk", w2), (p + ".c2.wpk_t", wt)])
         out[p + ".c2.cb"] = sa * (w64(s + "_conv2/b").reshape(-1) + w64(s + "_transform/b").reshape(-1)) + ha
 
     # --- conditioned stack (SN/main.py:126-187,219-229)
@@ -103,18 +152,21 @@ def fold_arrays(W, kind):
         if g["cin"] == 1:
             out[p + ".c1.w"] = w1.reshape(-1)
         else:
-            out[p + ".c1.wpk"] = pack_igemm(w1)
-        out[p + ".c2.wpk"] = pack_igemm(w64(s + "_conv2/w").reshape(-1, c) * sa)
+            emit(p + ".c1", [(p + ".c1.wpk", w1)])
+        w2 = w64(s + "_conv2/w").reshape(-1, c) * sa
         extra_bias = w64(s + "_conv2/b").reshape(-1)
         if g["cin"] == 1:
             out[p + ".c2.idw"] = w64(s + "_transform/w").reshape(-1) * sa
             extra_bias = extra_bias + w64(s + "_transform/b").reshape(-1)
+            emit(p + ".c2", [(p + ".c2.wpk", w2)])
         elif g["cin"] != c:
-            out[p + ".c2.wpk_t"] = pack_igemm(w64(s + "_transform/w").reshape(g["cin"], c) * sa)
+            emit(p + ".c2", [(p + ".c2.wpk", w2),
+                             (p + ".c2.wpk_t", w64(s + "_transform/w").reshape(g["cin"], c) * sa)])
             out[p + ".c2.idw"] = np.zeros(c)          # unused: the transform rides in the K loop
             extra_bias = extra_bias + w64(s + "_transform/b").reshape(-1)
         else:
             out[p + ".c2.idw"] = sa
+            emit(p + ".c2", [(p + ".c2.wpk", w2)])
         for cv, sc, sh, bias in ((1, s1, h1, 0.0), (2, sa, ha, extra_bias)):
             q = "%s_conv%d" % (s, cv)
             out["%s.c%d.ts" % (p, cv)] = (_cont_embed(W, g["hout"], q + "_temb") * sc).reshape(-1)
@@ -126,9 +178,9 @@ def fold_arrays(W, kind):
 
     # --- head (SN/main.py:232-242)
     s, h = _bn(W, "last_conv")
-    out["head.conv.wpk"] = pack_igemm(w64("last_conv/w").reshape(-1, 512) * s)
+    emit("head.conv", [("head.conv.wpk", w64("last_conv/w").reshape(-1, 512) * s)])
     out["head.conv.cb"] = h
-    out["head.dense.wpk"] = pack_igemm(w64("last_dense/w"), 256)
+    emit("head.dense", [("head.dense.wpk", w64("last_dense/w"))], 256)
     cb = np.zeros(256)
     cb[:spec.BINS] = w64("last_dense/b").reshape(-1)
     out["head.dense.cb"] = cb

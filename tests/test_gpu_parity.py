@@ -21,17 +21,30 @@ WAV_RMS_TOL = 1e-3
 
 
 @pytest.fixture(scope="module")
-def eng_d(lib_built, weights_denoiser):
+def _eng_d(lib_built, weights_denoiser):
     e = engine.Engine("denoiser", weights_denoiser)
     yield e
     e.close()
 
 
 @pytest.fixture(scope="module")
-def eng_s(lib_built, weights_separator):
+def _eng_s(lib_built, weights_separator):
     e = engine.Engine("separator", weights_separator)
     yield e
     e.close()
+
+
+# every test runs in both arithmetic modes of the conv kernels: exact f32 MFMA and split-f16 x3
+@pytest.fixture(params=["f32", "f16x3"])
+def eng_d(request, _eng_d):
+    _eng_d.set_precision(request.param)
+    return _eng_d
+
+
+@pytest.fixture(params=["f32", "f16x3"])
+def eng_s(request, _eng_s):
+    _eng_s.set_precision(request.param)
+    return _eng_s
 
 
 def exp2_inputs():

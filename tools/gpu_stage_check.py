@@ -26,7 +26,8 @@ def main():
     mix = O.trim_to_frames(O.normalise(synth.mixture(0, secs)))
     ca = O.normalise(synth.silent())
     cb = O.normalise(synth.noise_context(0))
-    eng = engine.Engine(kind, W)
+    prec = sys.argv[3] if len(sys.argv) > 3 else "f32"
+    eng = engine.Engine(kind, W, precision=prec)
     dev = eng.device
 
     # --- STFT
