@@ -545,7 +545,7 @@ int nhans_create(int model_kind, const void* blob, size_t nbytes, int device_id,
     c->cond_cols = off;
     // every array the launch sequences will dereference must be present with the right size
     std::vector<std::pair<std::string, size_t>> need = {
-        {"tw400", 800}, {"window", 400}, {"wsyn", 400}, {"zero", 64},
+        {"tw400", 800}, {"window", 400}, {"wsyn", 400}, {"zero", 16384},
         {"cond.w", (size_t)2 * kEmb * off}, {"cond.base", (size_t)off},
         {"head.conv.wpk", (size_t)5 * 512 * 512}, {"head.conv.cb", 512},
         {"head.dense.wpk", (size_t)26 * 512 * 256}, {"head.dense.cb", 256}, {"head.dense.idw", 256}};

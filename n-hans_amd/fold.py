@@ -119,7 +119,7 @@ def fold_arrays(W, kind, split_f16=True):
         seg = win[q * spec.HOP:(q + 1) * spec.HOP] ** 2
         den[:len(seg)] += seg
     out["wsyn"] = win / np.tile(den, -(-spec.WIN // spec.HOP))[:spec.WIN]
-    out["zero"] = np.zeros(64)
+    out["zero"] = np.zeros(16384)      # zero page: padded taps read their channels from here
 
     # --- embedding tower (SN/main.py:102-124,190-216)
     for i, g in enumerate(spec.tower_geometry()):
