@@ -51,6 +51,7 @@ class Flags(object):
     output = "./audio_examples/denoised.wav"
     compensate = 0.0
     ac = False
+    convert = False      # library calls keep the in-tree asserts; the CLI converts like the packaged tool
     Fs = Fs
     weights = os.environ.get("NHANS_WEIGHTS", "checkpoint")
     model_dir = os.environ.get("NHANS_MODEL_DIR", "./trained_model")
@@ -69,6 +70,35 @@ def read_wav(in_path):
         samples = samples.mean(axis=1)
     assert len(samples.shape) == 1
     return samples
+
+
+def read_wav_any(in_path):
+    """Format converter of the packaged tool (README.md:42: other formats are "automatically
+    converted" to 16 kHz / 16-bit PCM with sox; sox is not available, scipy does the same job):
+    any PCM/float wav at any rate -> what read_wav() would have returned for the converted file."""
+    rate, samples = wavread(in_path)
+    if rate == FLAGS.Fs and samples.dtype == np.int16:
+        return read_wav(in_path)
+    x = samples.astype(np.float64)
+    if samples.dtype == np.uint8:
+        x = (x - 128.0) * 256.0
+    elif samples.dtype == np.int32:
+        x = x / 65536.0
+    elif samples.dtype.kind == 'f':
+        x = x * 32768.0
+    if rate != FLAGS.Fs:
+        from math import gcd
+        from scipy.signal import resample_poly
+        g = gcd(int(FLAGS.Fs), int(rate))
+        x = resample_poly(x, FLAGS.Fs // g, rate // g, axis=0)
+    x = np.clip(np.round(x), -32768, 32767).astype(np.int16)
+    if x.ndim > 1:
+        x = x.mean(axis=1)
+    return x
+
+
+def _reader():
+    return read_wav_any if getattr(FLAGS, 'convert', False) else read_wav
 
 
 def normalise(samples):
@@ -104,7 +134,7 @@ def handle_signals(mixedpath, noisepospath, noisenegpath):
     """SN/apply.py:142-167: returns (pos, neg, mixed) float32; wav problems print
     'error in threads' and yield None, like the reference's bare except."""
     try:
-        mixedsamples = read_wav(mixedpath)
+        mixedsamples = _reader()(mixedpath)
         noisepossamples = _read_context(noisepospath)
         noisenegsamples = _read_context(noisenegpath)
         mixedsamples = trim_to_frames(normalise(mixedsamples))
@@ -118,7 +148,7 @@ def handle_signals(mixedpath, noisepospath, noisenegpath):
 def _read_context(path):
     if path is None or (os.path.basename(path) == "Silent.wav" and not os.path.exists(path)):
         return np.zeros(spec.MIN_CTX_SAMPLES, dtype=np.int16)
-    return extend_context(read_wav(path))
+    return extend_context(_reader()(path))
 
 
 # ------------------------------------------------------------------------------ engine / weights
@@ -190,6 +220,90 @@ def apply_separator(mixedpath, cleanpath, noisepath, save_to):
     wavwrite(save_to[:-12] + 'mixed_processed.wav', FLAGS.Fs, mixed_samples)
 
 
+# ------------------------------------------------------------------------------ demo / eval mode
+def _enhance_after_context(eng, mix_wav, ctx_a_wav, ctx_b_wav, extra_wavs=()):
+    """Shared by apply_demo and the evaluation reader (SN/apply.py:247-266, SN/reader.py:398-409):
+    the first Noise_Win frames of the two conditioning signals are the contexts, and the network
+    runs on the mixture's frames FROM Noise_Win ON, windowed as a clip of its own (zero rows before
+    frame Noise_Win, not the preceding frames).  Uses the stage-level C ABI.  Returns
+    (denoised_samples, mixed_samples, [iSTFT of each extra signal's frames from Noise_Win on],
+    logits, denoised_logmag)."""
+    import torch
+    dev = eng.device
+    wavs = [mix_wav] + list(extra_wavs)
+    flat = torch.from_numpy(np.concatenate([np.asarray(w, dtype=np.float32) for w in wavs])).to(dev)
+    off = [0]
+    for w in wavs:
+        off.append(off[-1] + len(w))
+    lm, ph = eng.stft_features(flat, off)
+    nfr = [int(eng.lib.nhans_num_frames(len(w))) for w in wavs]
+    t = nfr[0]
+    if t <= Noise_Win:
+        raise ValueError("recording has %d frames; more than %d are needed" % (t, Noise_Win))
+    ctx = torch.from_numpy(np.concatenate([ctx_a_wav, ctx_b_wav]).astype(np.float32)).to(dev)
+    cl, _ = eng.stft_features(ctx, [0, len(ctx_a_wav), len(ctx_a_wav) + len(ctx_b_wav)], Noise_Win, False)
+    emb = eng.embed(cl.view(2, Noise_Win, spec.BINS))
+    lm_s, ph_s = lm[Noise_Win:t].contiguous(), ph[Noise_Win:t].contiguous()
+    n = t - Noise_Win
+    logits, den = eng.mask_net(lm_s, [0, n], emb[0:1], emb[1:2])
+    den_wav, _ = eng.istft(den, ph_s, [0, n])
+    mix_rt, _ = eng.istft(lm_s, ph_s, [0, n])
+    extras, f0 = [], t
+    for k in nfr[1:]:
+        w, _ = eng.istft(lm[f0 + Noise_Win:f0 + k].contiguous(), ph[f0 + Noise_Win:f0 + k].contiguous(), [0, k - Noise_Win])
+        extras.append(w.cpu().numpy())
+        f0 += k
+    torch.cuda.synchronize(dev)
+    return den_wav.cpu().numpy(), mix_rt.cpu().numpy(), extras, logits.cpu().numpy(), den.cpu().numpy(), lm_s.cpu().numpy()
+
+
+def apply_demo(speechpath, pospath, negpath, save_to):
+    """Denoiser demo (SN/apply.py:212-336): mix clean speech with a positive and a negative noise
+    at 0 dB each, condition on the first 200 frames of the two (scaled) noises, enhance the rest.
+    Writes save_to and save_to[:-15] + 'mixed_demo.wav'."""
+    from . import mixing
+    _, pos_sig, neg_sig, mixed, _, _ = mixing.combine_signals(read_wav, speechpath, pospath, negpath)
+    den, mix_rt, _, _, _, _ = _enhance_after_context(get_engine(spec.DENOISER), mixed, pos_sig, neg_sig)
+    wavwrite(save_to, FLAGS.Fs, den)
+    wavwrite(save_to[:-15] + 'mixed_demo.wav', FLAGS.Fs, mix_rt)
+
+
+def apply_demo_separator(cleanpath, noisepath, save_to):
+    """Separator demo (SS/apply.py:179-285): mix two speakers at 0 dB; contexts are the first 200
+    frames of the interferer (noise*K -> noisecontextph) and of the target (clean -> cleancontextph)."""
+    from . import mixing
+    clean, noise_k, mixed, _ = mixing.combine_signals_separator(read_wav, cleanpath, noisepath)
+    den, mix_rt, _, _, _, _ = _enhance_after_context(get_engine(spec.SEPARATOR), mixed, noise_k, clean)
+    wavwrite(save_to, FLAGS.Fs, den)
+    wavwrite(save_to[:-15] + 'mixed_demo.wav', FLAGS.Fs, mix_rt)
+
+
+def evaluate_utterance(cleanpath, noisepospath, noisenegpath, dump_dir, modelname='nhans', step=0):
+    """Evaluation-reader pipeline for one (speech, pos noise, neg noise) triple: SN/reader.py:310-420
+    (eval branch, eval_stride 1) + SN/main.py:264-353.  Mixes at the reference's md5-derived SNRs,
+    runs the network on frames from context_frames on, writes the reference's five wavs
+    `<model>_<step>_<clean>_<pos>_<neg>_<snrp>_<snrn>_{mixed,denoised,target,posNoise,negNoise}.wav`
+    and returns the loss of SN/main.py:245-248 for this utterance."""
+    from . import mixing
+    target, pos_sig, neg_sig, mixed, snr_pos, snr_neg = mixing.combine_signals(
+        read_wav, cleanpath, noisepospath, noisenegpath, snrs=mixing.eval_snrs(cleanpath))
+    eng = get_engine(spec.DENOISER)
+    den, mix_rt, extras, _, den_lm, _ = _enhance_after_context(eng, mixed, pos_sig, neg_sig,
+                                                               extra_wavs=(target, pos_sig, neg_sig))
+    import torch
+    tgt_lm, _ = eng.stft_features(torch.from_numpy(np.asarray(target, dtype=np.float32)).to(eng.device), [0, len(target)], 0, False)
+    tgt_lm = tgt_lm[Noise_Win:].cpu().numpy()
+    imp = np.linspace(2, 1, spec.BINS, dtype=np.float32).reshape(1, spec.BINS)
+    loss = float(np.mean(np.mean(np.square(den_lm - tgt_lm) * imp, axis=1)))
+    base = [os.path.basename(p)[:-4] for p in (cleanpath, noisepospath, noisenegpath)]
+    os.makedirs(dump_dir, exist_ok=True)
+    for kind, w in (('mixed', mix_rt), ('denoised', den), ('target', extras[0]), ('posNoise', extras[1]),
+                    ('negNoise', extras[2])):
+        name = '{}_{}_{}_{}_{}_{}_{}_{}.wav'.format(modelname, step, base[0], base[1], base[2], snr_pos, snr_neg, kind)
+        wavwrite(os.path.join(dump_dir, name), FLAGS.Fs, w)
+    return loss
+
+
 # ------------------------------------------------------------------------------ CLI
 def _parse(argv, prog):
     p = argparse.ArgumentParser(prog=prog)
@@ -201,6 +315,9 @@ def _parse(argv, prog):
     p.add_argument('--ac', action='store_true')
     p.add_argument('--weights', default=FLAGS.weights, choices=['checkpoint', 'synthetic'])
     p.add_argument('--model_dir', default=FLAGS.model_dir)
+    p.add_argument('--no-convert', dest='convert', action='store_false', default=True,
+                   help='reject inputs that are not 16 kHz int16 PCM (in-tree reference behaviour) '
+                        'instead of converting them (packaged-tool behaviour, README.md:42)')
     a = p.parse_args(argv)
     for k, v in vars(a).items():
         setattr(FLAGS, k, v)

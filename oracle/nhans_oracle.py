@@ -305,3 +305,54 @@ def enhance(mixed_wav, ctx_a_wav, ctx_b_wav, W, kind="denoiser", batch=8, frames
         factor = snr_est / 20 if ac else compensate
         res["compensated_wav"] = res["denoised_wav"] + removed * factor
     return res
+
+
+# ----------------------------------------------------------------------------- demo / eval mode
+def _fit(noise, n):
+    """SN/apply.py:58-72 -- repeat the noise while shorter than the speech, cut if longer."""
+    nse = noise
+    while n - len(nse) > 0:
+        nse = np.concatenate([nse, noise[:n - len(nse)]], axis=0)
+    return noise[:n] if n - len(noise) < 0 else nse
+
+
+def domixing(clean, pos, neg, snr_pos, snr_neg):
+    """SN/apply.py:56-104 (== SN/reader.py:128-176), including the re-use of the normalised `mixed`
+    when "normalising" target and the noise signals (:98-102)."""
+    nse_pos, nse_neg = _fit(pos, len(clean)), _fit(neg, len(clean))
+    power = lambda x: sum(abs(x) * abs(x)) / x.shape[0]
+    ps, pp, pn = power(clean), power(nse_pos), power(nse_neg)
+    k_pos = 1 if pp == 0 else np.sqrt((ps / pp) * pow(10, -snr_pos / 10.0))
+    k_neg = 1 if pn == 0 else np.sqrt((ps / pn) * pow(10, -snr_neg / 10.0))
+    pos_s, neg_s = k_pos * nse_pos, k_neg * nse_neg
+    mixed = clean + pos_s + neg_s
+    mixed = mixed / (max(abs(mixed)) + 0.000001)
+    peak = max(abs(mixed)) + 0.000001
+    return mixed, (clean + pos_s) / peak, k_pos, k_neg, pos_s / peak, neg_s / peak
+
+
+def demo_signals(clean_i16, pos_i16, neg_i16, snr_pos=0, snr_neg=0):
+    """combine_signals of SN/apply.py:107-135 on already-read int16 arrays."""
+    clean = trim_to_frames(normalise(clean_i16))
+    mixed, target, _, _, pos_sig, neg_sig = domixing(clean, normalise(pos_i16), normalise(neg_i16), snr_pos, snr_neg)
+    return target, pos_sig, neg_sig, mixed
+
+
+def enhance_after_context(mixed, ctx_a_wav, ctx_b_wav, W, kind="denoiser", frames=None):
+    """apply_demo / eval reader (SN/apply.py:247-266,318-336; SN/reader.py:398-409): contexts = first
+    200 frames of the conditioning signals, network on mix frames from 200 on, windowed on their own."""
+    lm, ph = logmag_phase(stft(mixed))
+    la, _ = logmag_phase(stft(ctx_a_wav))
+    lb, _ = logmag_phase(stft(ctx_b_wav))
+    ea, eb = embed_tower(context(la)[None], W), embed_tower(context(lb)[None], W)
+    lm_s, ph_s = lm[NOISE_WIN:], ph[NOISE_WIN:]
+    win = strided_crop(lm_s, MIX_WIN)
+    sel = np.arange(lm_s.shape[0]) if frames is None else np.asarray(frames)
+    logits = np.zeros_like(lm_s)
+    for i in range(0, len(sel), 8):
+        idx = sel[i:i + 8]
+        o, _ = mask_net(win[idx], np.repeat(ea, len(idx), 0), np.repeat(eb, len(idx), 0), W, kind)
+        logits[idx] = o
+    den = lm_s + logits
+    return dict(logmag=lm_s, phase=ph_s, logits=logits, denoised=den, denoised_wav=recover_samples(den, ph_s),
+                mixed_wav=recover_samples(lm_s, ph_s))

@@ -13,5 +13,7 @@ setup(
     entry_points={"console_scripts": [
         "nhans_denoiser = nhans_amd.apply:main",
         "nhans_separator = nhans_amd.apply:main_separator",
+        "load_denoiser = nhans_amd.load_model:main",
+        "load_separator = nhans_amd.load_model:main_separator",
     ]},
 )

@@ -264,3 +264,52 @@ def test_apply_entry_points_write_reference_files(eng_d, eng_s, tmp_path, capsys
     r, s = wavfile.read(sep)
     assert r == 16000 and s.dtype == np.float32 and len(s) == 15920
     assert os.path.exists(str(tmp_path / "sep_mixed_processed.wav"))
+
+
+def test_demo_and_eval_mode(_eng_d, _eng_s, weights_denoiser, tmp_path):
+    """apply_demo / apply_demo_separator / evaluate_utterance: contexts = first 200 frames of the
+    conditioning signals, network on the frames after them (SN/apply.py:212-336, SN/reader.py:398-420,
+    SN/main.py:264-353)."""
+    from scipy.io import wavfile
+    from nhans_amd import mixing
+    _eng_d.set_precision("f16x3")
+    _eng_s.set_precision("f16x3")
+    apply.set_engine("denoiser", _eng_d)
+    apply.set_engine("separator", _eng_s)
+    paths = {}
+    for name, sig in (("speech", synth.mixture(30, 2.6)), ("pos", synth.noise_context(30, 1.0)),
+                      ("neg", synth.speaker_context(30, 3.0)), ("spk", synth.speaker_context(31, 2.6, low=False))):
+        paths[name] = str(tmp_path / (name + ".wav"))
+        wavfile.write(paths[name], 16000, sig)
+    out = str(tmp_path / "clip_output_demo.wav")
+    apply.apply_demo(paths["speech"], paths["pos"], paths["neg"], out)
+    r, den = wavfile.read(out)
+    r2, mix = wavfile.read(str(tmp_path / "clip_mixed_demo.wav"))          # save_to[:-15] + 'mixed_demo.wav'
+    T = 1 + (len(apply.trim_to_frames(np.zeros(len(synth.mixture(30, 2.6)), np.float32))) - 400) // 160
+    assert r == r2 == 16000 and den.dtype == np.float32 and len(den) == len(mix) == (T - 200 - 1) * 160 + 400
+    target, pos_sig, neg_sig, mixed = O.demo_signals(*(apply.read_wav(paths[k]) for k in ("speech", "pos", "neg")))
+    ref = O.enhance_after_context(mixed, pos_sig, neg_sig, weights_denoiser, "denoiser", frames=[0, 1, 30, T - 201])
+    assert np.sqrt(np.mean((mix - ref["mixed_wav"]) ** 2)) < WAV_RMS_TOL
+    got = apply._enhance_after_context(_eng_d, mixed, pos_sig, neg_sig)
+    assert np.abs(got[3][[0, 1, 30, T - 201]] - ref["logits"][[0, 1, 30, T - 201]]).max() < 5 * LOGIT_TOL
+    assert np.array_equal(got[0], den)
+    # frame `200` is windowed with zero rows before it, not with frames 183..199
+    full = _eng_d.enhance([mixed], [pos_sig], [neg_sig], want_mixed=False, taps=True)
+    assert np.abs(full["logits"][200] - got[3][0]).max() > 1e-3
+    assert np.abs(full["logits"][200 + 30] - got[3][30]).max() < 1e-6          # interior frames agree
+    # separator demo
+    sout = str(tmp_path / "sep_output_demo.wav")
+    apply.apply_demo_separator(paths["spk"], paths["neg"], sout)
+    rs, sden = wavfile.read(sout)
+    assert rs == 16000 and np.isfinite(sden).all() and os.path.exists(str(tmp_path / "sep_mixed_demo.wav"))
+    # evaluation reader: five wavs with the reference's naming, loss finite
+    loss = apply.evaluate_utterance(paths["speech"], paths["pos"], paths["neg"], str(tmp_path / "wav_dump"), "nhans", 5000)
+    sp, sn = mixing.eval_snrs(paths["speech"])
+    names = sorted(os.listdir(str(tmp_path / "wav_dump")))
+    assert names == sorted("nhans_5000_speech_pos_neg_%d_%d_%s.wav" % (sp, sn, k)
+                           for k in ("mixed", "denoised", "target", "posNoise", "negNoise"))
+    assert np.isfinite(loss) and loss > 0
+    _, tw = wavfile.read(str(tmp_path / "wav_dump" / ("nhans_5000_speech_pos_neg_%d_%d_target.wav" % (sp, sn))))
+    tgt = mixing.combine_signals(apply.read_wav, paths["speech"], paths["pos"], paths["neg"], snrs=(sp, sn))[0]
+    lt, pt = O.logmag_phase(O.stft(tgt))
+    assert np.sqrt(np.mean((tw - O.recover_samples(lt[200:], pt[200:])) ** 2)) < WAV_RMS_TOL

@@ -205,3 +205,85 @@ def test_synthetic_audio_is_deterministic():
     assert a.dtype == np.int16 and np.array_equal(a, b) and np.abs(a).max() == 32767
     assert len(synth.noise_context(0)) == 48000 >= spec.MIN_CTX_SAMPLES
     assert not np.array_equal(synth.mixture(4, 0.5), a)
+
+
+# ------------------------------------------------------------------------------ converter / load_*
+def test_format_converter(tmp_path):
+    t = np.arange(8000) / 8000.0
+    x = np.sin(2 * np.pi * 440 * t)
+    p = str(tmp_path / "a.wav")
+    wavfile.write(p, 16000, np.round(x * 20000).astype(np.int16))
+    assert np.array_equal(apply.read_wav_any(p), apply.read_wav(p))           # already standard: untouched
+    wavfile.write(p, 8000, x.astype(np.float32))                              # 8 kHz float -> 16 kHz int16
+    y = apply.read_wav_any(p)
+    assert y.dtype == np.int16 and len(y) == 16000
+    ref = np.sin(2 * np.pi * 440 * np.arange(16000) / 16000.0) * 32768
+    assert np.abs(y[2000:14000] - ref[2000:14000]).max() < 400
+    wavfile.write(p, 48000, np.stack([np.round(np.tile(x, 6) * 2 ** 30).astype(np.int32)] * 2, 1))   # 48 kHz int32 stereo
+    z = apply.read_wav_any(p)
+    assert z.ndim == 1 and len(z) == 16000 and 15000 < np.abs(z).max() < 17000
+    with pytest.raises(AssertionError):
+        apply.read_wav(p)
+    a = apply._parse(["--input", p, "--neg", p, "--output", "o_denoised.wav"], "nhans_denoiser")
+    assert a.convert is True and apply._reader() is apply.read_wav_any
+    apply._parse(["--input", p, "--neg", p, "--output", "o_denoised.wav", "--no-convert"], "nhans_denoiser")
+    assert apply._reader() is apply.read_wav
+    apply.FLAGS.convert = False
+
+
+def test_load_model_verifies_user_checkpoint(tmp_path, weights_denoiser, capsys):
+    from nhans_amd import load_model
+    name, size, sha = load_model.BUNDLES["denoiser"]
+    assert (name, size) == ("81448_0-1000000", 115999524) and len(sha) == 64
+    with pytest.raises(FileNotFoundError):
+        load_model.verify("denoiser", str(tmp_path))
+    os.symlink(os.path.join(GOLDEN, "denoiser.index"), str(tmp_path / (name + ".index")))
+    data = str(tmp_path / (name + ".data-00000-of-00001"))
+    open(data, "w").write("version https://git-lfs.github.com/spec/v1\noid sha256:%s\nsize %d\n" % (sha, size))
+    with pytest.raises(FileNotFoundError, match="LFS"):
+        load_model.verify("denoiser", str(tmp_path))
+    ent = tfbundle.read_index(os.path.join(GOLDEN, "denoiser.index"))
+    buf = bytearray(size)
+    for n, e in ent.items():
+        buf[e["offset"]:e["offset"] + e["size"]] = weights_denoiser[n].tobytes()
+    open(data, "wb").write(buf)
+    with pytest.raises(ValueError, match="sha256"):          # right size, not the trained weights
+        load_model.verify("denoiser", str(tmp_path))
+    load_model.main(["--model_dir", str(tmp_path), "--no-hash"])
+    assert "571 tensors, 28999881 parameters" in capsys.readouterr().out
+
+
+# ------------------------------------------------------------------------------ demo / eval mixing
+def test_domixing_matches_oracle_and_reference_quirks():
+    from nhans_amd import mixing
+    from oracle import nhans_oracle as O
+    sig = {"c": synth.mixture(7, 3.0), "p": synth.noise_context(7, 1.0), "n": synth.speaker_context(7, 4.0)}
+    t1, p1, n1, m1 = O.demo_signals(sig["c"], sig["p"], sig["n"])
+    t2, p2, n2, m2, sp, sn = mixing.combine_signals(lambda k: sig[k], "c", "p", "n")
+    for a, b in ((t1, t2), (p1, p2), (n1, n2), (m1, m2)):
+        assert a.dtype == np.float32 and np.array_equal(a, b)
+    assert (int(sp), int(sn)) == (0, 0) and len(m2) == 47920 == len(p2) == len(n2)      # trimmed, noise tiled/cut
+    assert abs(np.abs(m2).max() - 1.0) < 1e-5
+    assert np.abs(t2).max() > 1.2            # sic: target is divided by the NORMALISED mixture's peak
+    # 0 dB: scaled noise power == speech power (before the final normalisation they share one factor)
+    clean = O.trim_to_frames(O.normalise(sig["c"]))
+    assert abs(np.mean(p2.astype(np.float64) ** 2) / np.mean(clean.astype(np.float64) ** 2) - 1) < 1e-3
+    # evaluation reader: md5-derived SNRs are deterministic and in the table
+    a, b = mixing.eval_snrs("/data/test/6930-76324-0008.wav")
+    assert (a, b) == mixing.eval_snrs(b"/data/test/6930-76324-0008.wav") and a in mixing.SNRS_DENOISER and b in mixing.SNRS_DENOISER
+    t3, _, n3, m3, sp3, sn3 = mixing.combine_signals(lambda k: sig[k], "c", "p", "n", snrs=(8, -3))
+    ratio = np.mean(n3.astype(np.float64) ** 2) / np.mean(np.asarray(n2, np.float64) ** 2)
+    assert (int(sp3), int(sn3)) == (8, -3) and not np.array_equal(m3, m2) and ratio > 1.0
+
+
+def test_separator_mixing_and_trim_quirk():
+    from nhans_amd import mixing
+    sig = {"c": synth.speaker_context(1, 2.0, low=False), "n": synth.speaker_context(1, 1.0, low=True)}
+    clean, noise_k, mixed, snr = mixing.combine_signals_separator(lambda k: sig[k], "c", "n")
+    assert len(clean) == len(mixed) == 31920 and len(noise_k) == 16000 and int(snr) == 0
+    assert abs(np.abs(mixed).max() - 1.0) < 1e-5
+    # a clean recording that already holds a whole number of frames is emptied by the reference's
+    # unconditional `[:-0]` slice (SS/apply.py:98); reproduced, and it fails loudly downstream
+    sig["c"] = sig["c"][:400 + 160 * 50]
+    with pytest.raises(Exception):
+        mixing.combine_signals_separator(lambda k: sig[k], "c", "n")
