@@ -39,13 +39,9 @@ __global__ void __launch_bounds__(256) direct_conv64(const DirectArgs a) {
         const int clip = a.img_clip ? a.img_clip[b] : 0;
         const float4 cb = *reinterpret_cast<const float4*>(a.cb + (size_t)clip * a.cb_stride + c);
         acc.x += cb.x; acc.y += cb.y; acc.z += cb.z; acc.w += cb.w;
-        if (a.ts) {
-            const float4 t = *reinterpret_cast<const float4*>(a.ts + ho * 64 + c);
+        if (a.tf) {
+            const float4 t = *reinterpret_cast<const float4*>(a.tf + (size_t)rem * 64 + c);
             acc.x += t.x; acc.y += t.y; acc.z += t.z; acc.w += t.w;
-        }
-        if (a.fs) {
-            const float4 f = *reinterpret_cast<const float4*>(a.fs + wo * 64 + c);
-            acc.x += f.x; acc.y += f.y; acc.z += f.z; acc.w += f.w;
         }
         if (a.relu) {
             acc.x = fmaxf(acc.x, 0.f); acc.y = fmaxf(acc.y, 0.f);

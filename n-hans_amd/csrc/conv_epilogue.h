@@ -1,0 +1,193 @@
+// Fused N-HANS block epilogue shared by the implicit-GEMM convolution kernels (contract in
+// conv_igemm.hip / nhans_kernels.h):
+//     v   = acc * ws[n] + cb[clip(b), n] + tf[(ho, wo), n]              (ws: split-f16 mode only)
+//     aux = v                                                            (optional pre-residual tap)
+//     v  += idw[n] * residual                                            (tensor / 1-channel image)
+//     out = relu ? max(v, 0) : v      as f32 NHWC or split NHWC (hi/lo halfs)
+//
+// The accumulator tile goes through LDS once so that the global side is fully coalesced: the K loop
+// leaves each lane with 4 consecutive channels of ONE pixel per register quad (the weights are the
+// row operand of the MFMAs), which is ideal for a 16-byte LDS write but would scatter 8-16 byte
+// pieces over 32 pixels per global store instruction -- measured as 30 % of the kernel time.  After
+// the transpose a wavefront owns whole pixel rows: 32 consecutive lanes cover 128 consecutive
+// channels, every table / residual read and every output write moves full 128-byte lines.
+#pragma once
+#include "nhans_kernels.h"
+
+namespace nhans {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));   // native vector: stays in registers
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float split_load(const float* base, size_t row_floats, int n) {
+    // value (hi + lo) of channel n of a split-NHWC pixel whose line starts at base + row_floats
+    const _Float16* p = reinterpret_cast<const _Float16*>(base + row_floats) + (n >> 5) * 64 + (n & 31);
+    return (float)p[0] + (float)p[32];
+}
+
+// LDS bytes the epilogue needs for a BMROWS x BNCOLS tile (accumulator tile padded by 4 floats per
+// row against bank conflicts + one int4 of row info per pixel)
+template <int BMROWS, int BNCOLS> constexpr size_t conv_epilogue_lds_bytes() {
+    return (size_t)BMROWS * (BNCOLS + 4) * sizeof(float) + (size_t)BMROWS * sizeof(int4);
+}
+
+// Row-major sweep of the epilogue for one thread = (pixel row within a pass, 4 channels n..n+3).
+// IDM: 0 none, 1 split-NHWC tensor, 2 f32 tensor, 3 one-channel image; OUTS: split-NHWC output.
+// Passes are processed in groups: every load of a group is issued before its first store, so a group
+// costs one memory round trip (the residual may alias the output -- identity blocks are written in
+// place -- which would otherwise force the compiler to finish pass p before starting pass p+1).
+template <int PREC, int IDM, int OUTS, int PP, int PASSES, int LDC>
+__device__ __forceinline__ void conv_epilogue_sweep(const ConvArgs& a, const float* ct, const int4* rowinfo, int m0,
+                                                    int prow, int c4, int n) {
+    constexpr int GP = PASSES < 8 ? PASSES : 8;
+    static_assert(PASSES % GP == 0, "pass grouping");
+    const int f_tf = a.tf ? 1 : 0;
+    const float* __restrict__ cbp = a.cb;
+    const float* __restrict__ tfp = a.tf ? a.tf : a.zero;     // an absent table reads the zero page
+    f32x4 wsv = {1.f, 1.f, 1.f, 1.f}, idwv = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (PREC == 1) wsv = *reinterpret_cast<const f32x4*>(a.ws + n);
+    if constexpr (IDM != 0) idwv = *reinterpret_cast<const f32x4*>(a.idw + n);
+    const int hoff = (n >> 5) * 64 + (n & 31);                // half index inside a split-NHWC pixel
+    const float lo_clamp = a.relu ? 0.f : -3.0e38f;           // branch-free ReLU
+#pragma unroll 1
+    for (int pg = 0; pg < PASSES; pg += GP) {
+        f32x4 yv[GP];
+#pragma unroll
+        for (int u = 0; u < GP; ++u) {
+            const int p = (pg + u) * PP + prow;
+            const int m = m0 + p;
+            const int mc = m < a.M ? m : a.M - 1;
+            const int4 ri = rowinfo[p];
+            const f32x4 av = *reinterpret_cast<const f32x4*>(ct + p * LDC + c4 * 4);
+            const f32x4 c = *reinterpret_cast<const f32x4*>(cbp + ri.x + n);
+            const f32x4 t = *reinterpret_cast<const f32x4*>(tfp + (ri.y + n) * f_tf);
+            f32x4 idv = {0.f, 0.f, 0.f, 0.f};
+            if constexpr (IDM == 1) {
+                const _Float16* hp = reinterpret_cast<const _Float16*>(a.id + (size_t)mc * a.id_ld) + hoff;
+                const f16x4 h = *reinterpret_cast<const f16x4*>(hp);
+                const f16x4 l = *reinterpret_cast<const f16x4*>(hp + 32);
+                idv = f32x4{(float)h.x + (float)l.x, (float)h.y + (float)l.y, (float)h.z + (float)l.z,
+                            (float)h.w + (float)l.w};
+            } else if constexpr (IDM == 2) {
+                idv = *reinterpret_cast<const f32x4*>(a.id + (size_t)mc * a.id_ld + n);
+            } else if constexpr (IDM == 3) {
+                const float sv = a.id[ri.w];
+                idv = f32x4{sv, sv, sv, sv};
+            }
+            const f32x4 y = ((av * wsv + c) + t) + idwv * idv;
+            yv[u] = f32x4{fmaxf(y.x, lo_clamp), fmaxf(y.y, lo_clamp), fmaxf(y.z, lo_clamp), fmaxf(y.w, lo_clamp)};
+        }
+#pragma unroll
+        for (int u = 0; u < GP; ++u) {
+            const int m = m0 + (pg + u) * PP + prow;
+            const f32x4 y = yv[u];
+            if (m < a.M) {
+                if constexpr (OUTS) {
+                    f16x4 h, l;
+                    float yc;
+                    yc = fminf(fmaxf(y.x, -65504.f), 65504.f); h.x = (_Float16)yc; l.x = (_Float16)(yc - (float)h.x);
+                    yc = fminf(fmaxf(y.y, -65504.f), 65504.f); h.y = (_Float16)yc; l.y = (_Float16)(yc - (float)h.y);
+                    yc = fminf(fmaxf(y.z, -65504.f), 65504.f); h.z = (_Float16)yc; l.z = (_Float16)(yc - (float)h.z);
+                    yc = fminf(fmaxf(y.w, -65504.f), 65504.f); h.w = (_Float16)yc; l.w = (_Float16)(yc - (float)h.w);
+                    _Float16* dst = reinterpret_cast<_Float16*>(a.out + (size_t)m * a.ldo) + hoff;
+                    *reinterpret_cast<f16x4*>(dst) = h;
+                    *reinterpret_cast<f16x4*>(dst + 32) = l;
+                } else {
+                    *reinterpret_cast<f32x4*>(a.out + (size_t)m * a.ldo + n) = y;
+                }
+            }
+        }
+    }
+}
+
+// acc[i][j]: 32x32 MFMA tile (i: pixels, j: channels) of the wave whose tile-local origin is
+// (row_base, col_base); n_tile0: first channel of the workgroup tile; the caller has passed a
+// workgroup barrier after its last LDS read of the K loop.
+template <int TM, int TN, int PREC, int NTHREADS, int BMROWS, int BNCOLS>
+__device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[TM][TN], float* smem, int m0,
+                                              int row_base, int col_base, int n_tile0, int tid, int lane) {
+    constexpr int LDC = BNCOLS + 4;
+    constexpr int C4 = BNCOLS / 4;                    // threads along the channels of one pixel
+    constexpr int PP = NTHREADS / C4;                 // pixels per pass
+    constexpr int PASSES = BMROWS / PP;
+    float* ct = smem;
+    int4* rowinfo = reinterpret_cast<int4*>(smem + BMROWS * LDC);
+
+    // 1. accumulators -> LDS tile [pixel][channel]; lane l: pixel l&31, channels 8g + 4(l>>5) + {0..3}
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 v = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+                *reinterpret_cast<f32x4*>(ct + (row_base + i * 32 + (lane & 31)) * LDC + col_base + j * 32 + 8 * g +
+                                          4 * (lane >> 5)) = v;
+            }
+    // 2. per-pixel (clip, h, w, 1-channel residual index)
+    if (tid < BMROWS) {
+        int m = m0 + tid;
+        if (m >= a.M) m = a.M - 1;
+        const uint32_t b = fd_div((uint32_t)m, a.fdHoWo);
+        const uint32_t rem = (uint32_t)m - b * a.fdHoWo.d;
+        const uint32_t ho = fd_div(rem, a.fdWo);
+        const uint32_t wo = rem - ho * a.fdWo.d;
+        const int clip = a.img_clip ? a.img_clip[b] : 0;
+        const int ids = (int)((b * a.idH + ho * a.idsh) * a.idW + wo * a.idsw);
+        rowinfo[tid] = make_int4(clip * a.cb_stride, (int)rem * a.N, 0, ids);
+    }
+    __syncthreads();
+
+    // 3. row-major sweep: thread = (pixel within pass, 4 channels)
+    const int c4 = tid % C4, prow = tid / C4;
+    const int n = n_tile0 + c4 * 4;
+    const int f_tf = a.tf ? 1 : 0;
+    const bool id_split = a.id_mode == 1 && a.id_split;
+    const float* __restrict__ cbp = a.cb;
+    const float* __restrict__ tfp = a.tf ? a.tf : a.zero;     // an absent table reads the zero page
+    const bool vec = (a.Nreal == a.N) && !a.aux && (a.out_split || (a.ldo & 3) == 0) &&
+                     (a.id_mode != 1 || id_split || (a.id_ld & 3) == 0);
+    if (vec) {
+        // residual mode / output layout are resolved once, outside the loops: the sweep below is one
+        // straight-line block per group of passes, so all its loads issue before the first wait
+        const int mode = (a.id_mode == 1 ? (id_split ? 1 : 2) : a.id_mode == 2 ? 3 : 0) * 2 + (a.out_split ? 1 : 0);
+        switch (mode) {
+            case 0: conv_epilogue_sweep<PREC, 0, 0, PP, PASSES, LDC>(a, ct, rowinfo, m0, prow, c4, n); break;
+            case 1: conv_epilogue_sweep<PREC, 0, 1, PP, PASSES, LDC>(a, ct, rowinfo, m0, prow, c4, n); break;
+            case 2: conv_epilogue_sweep<PREC, 1, 0, PP, PASSES, LDC>(a, ct, rowinfo, m0, prow, c4, n); break;
+            case 3: conv_epilogue_sweep<PREC, 1, 1, PP, PASSES, LDC>(a, ct, rowinfo, m0, prow, c4, n); break;
+            case 4: conv_epilogue_sweep<PREC, 2, 0, PP, PASSES, LDC>(a, ct, rowinfo, m0, prow, c4, n); break;
+            case 5: conv_epilogue_sweep<PREC, 2, 1, PP, PASSES, LDC>(a, ct, rowinfo, m0, prow, c4, n); break;
+            case 6: conv_epilogue_sweep<PREC, 3, 0, PP, PASSES, LDC>(a, ct, rowinfo, m0, prow, c4, n); break;
+            default: conv_epilogue_sweep<PREC, 3, 1, PP, PASSES, LDC>(a, ct, rowinfo, m0, prow, c4, n); break;
+        }
+    } else {
+        // ragged output (last_dense: 201 of 256 columns, unaligned rows, optional pre-residual tap)
+        for (int ps = 0; ps < PASSES; ++ps) {
+            const int p = ps * PP + prow;
+            const int m = m0 + p;
+            if (m >= a.M) continue;
+            const int4 ri = rowinfo[p];
+            const float idsv = a.id_mode == 2 ? a.id[ri.w] : 0.f;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int ne = n + e;
+                if (ne >= a.Nreal) continue;
+                float x = ct[p * LDC + c4 * 4 + e];
+                if constexpr (PREC == 1) x *= a.ws[ne];
+                x = (x + cbp[ri.x + ne]) + tfp[(ri.y + ne) * f_tf];
+                float y = x;
+                if (a.id_mode == 1)
+                    y += a.idw[ne] * (id_split ? split_load(a.id, (size_t)m * a.id_ld, ne) : a.id[(size_t)m * a.id_ld + ne]);
+                else if (a.id_mode == 2) y += a.idw[ne] * idsv;
+                if (a.relu) y = fmaxf(y, 0.f);
+                if (a.aux) a.aux[(size_t)m * a.aux_ld + ne] = x;
+                a.out[(size_t)m * a.ldo + ne] = y;
+            }
+        }
+    }
+}
+
+}  // namespace nhans

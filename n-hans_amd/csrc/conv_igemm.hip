@@ -38,22 +38,12 @@
 //     vertically adjacent tiles re-read the same input rows for neighbouring taps.
 //   * Epilogue: per-row (clip, h, w) is staged once in LDS; all table / residual loads of a row
 //     group are issued branch-free before the first use; stores follow.
-#include "nhans_kernels.h"
+#include "conv_epilogue.h"
 #include <cstdlib>
 
 namespace nhans {
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));   // native vector: stays in registers
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-
 constexpr int BM = 128, BK = 32, LDA = 36;
-
-__device__ __forceinline__ float split_load(const float* base, size_t row_floats, int n) {
-    // value (hi + lo) of channel n of a split-NHWC pixel whose line starts at base + row_floats
-    const _Float16* p = reinterpret_cast<const _Float16*>(base + row_floats) + (n >> 5) * 64 + (n & 31);
-    return (float)p[0] + (float)p[32];
-}
 
 template <int BN, int WM, int WN, int PREC, int ABL = 0>   // ABL: timing ablations (tools/ablate.py)
 __global__ void __launch_bounds__(256) conv_igemm(const ConvArgs a) {
@@ -328,113 +318,9 @@ __global__ void __launch_bounds__(256) conv_igemm(const ConvArgs a) {
 #undef NH_COMPUTE_H3
 #undef NH_COMPUTE
 
-    // ---- epilogue.  The weights are the row operand of the MFMAs, so the accumulator tile is
-    // C^T[n][m]: lane l holds pixel m = l&31 of the tile and, in registers 4g..4g+3, the four
-    // CONSECUTIVE channels n = 8g + 4(l>>5) + {0..3}.  Everything below is therefore 16-byte
-    // vector work per pixel: tables, residual and the output row (f32 or split hi/lo halfs).
-    int4* rowinfo = reinterpret_cast<int4*>(smem);
-    if (tid < BM) {
-        int m = m0 + tid;
-        if (m >= a.M) m = a.M - 1;
-        const uint32_t b = fd_div((uint32_t)m, a.fdHoWo);
-        const uint32_t rem = (uint32_t)m - b * a.fdHoWo.d;
-        const uint32_t ho = fd_div(rem, a.fdWo);
-        const uint32_t wo = rem - ho * a.fdWo.d;
-        const int clip = a.img_clip ? a.img_clip[b] : 0;
-        const int ids = (int)((b * a.idH + ho * a.idsh) * a.idW + wo * a.idsw);
-        rowinfo[tid] = make_int4(clip * a.cb_stride, (int)ho * a.N, (int)wo * a.N, ids);
-    }
-    __syncthreads();
-    const int nbase = nt * BN + wn * TN * 32 + 4 * (lane >> 5);
-    const int f_ts = a.ts ? 1 : 0, f_fs = a.fs ? 1 : 0;
-    const bool id_split = a.id_mode == 1 && a.id_split;
-    const float* __restrict__ cbp = a.cb;
-    const float* __restrict__ tsp = a.ts ? a.ts : a.zero;     // absent tables read the zero page
-    const float* __restrict__ fsp = a.fs ? a.fs : a.zero;
-    const bool vec = (a.Nreal == a.N) && !a.aux && (a.out_split || (a.ldo & 3) == 0) &&
-                     (a.id_mode != 1 || id_split || (a.id_ld & 3) == 0);
-    typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-        const int row = wm * TM * 32 + i * 32 + (lane & 31);
-        const int4 ri = rowinfo[row];
-        const int m = m0 + row;
-        const int mc = m < a.M ? m : a.M - 1;
-        const float idsv = a.id_mode == 2 ? a.id[ri.w] : 0.f;
-        if (vec) {
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                f32x4 x[4], idv[4];
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {          // issue every load of this 32-channel tile first
-                    const int n = nbase + j * 32 + 8 * g;
-                    const f32x4 c = *reinterpret_cast<const f32x4*>(cbp + ri.x + n);
-                    const f32x4 t = *reinterpret_cast<const f32x4*>(tsp + (ri.y + n) * f_ts);
-                    const f32x4 f = *reinterpret_cast<const f32x4*>(fsp + (ri.z + n) * f_fs);
-                    f32x4 av = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
-                    if constexpr (PREC == 1) av *= *reinterpret_cast<const f32x4*>(a.ws + n);
-                    x[g] = ((av + c) + t) + f;
-                    if (a.id_mode == 1) {
-                        if (id_split) {
-                            const _Float16* hp = reinterpret_cast<const _Float16*>(a.id + (size_t)mc * a.id_ld) +
-                                                 (n >> 5) * 64 + (n & 31);
-                            const f16x4 h = *reinterpret_cast<const f16x4*>(hp);
-                            const f16x4 l = *reinterpret_cast<const f16x4*>(hp + 32);
-                            idv[g] = f32x4{(float)h.x + (float)l.x, (float)h.y + (float)l.y,
-                                           (float)h.z + (float)l.z, (float)h.w + (float)l.w};
-                        } else {
-                            idv[g] = *reinterpret_cast<const f32x4*>(a.id + (size_t)mc * a.id_ld + n);
-                        }
-                    } else {
-                        idv[g] = f32x4{idsv, idsv, idsv, idsv};
-                    }
-                }
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int n = nbase + j * 32 + 8 * g;
-                    f32x4 y = x[g];
-                    if (a.id_mode) y += *reinterpret_cast<const f32x4*>(a.idw + n) * idv[g];
-                    if (a.relu) y = f32x4{fmaxf(y.x, 0.f), fmaxf(y.y, 0.f), fmaxf(y.z, 0.f), fmaxf(y.w, 0.f)};
-                    if (m < a.M) {
-                        if (a.out_split) {
-                            f16x4 h, l;
-                            float yc;
-                            yc = fminf(fmaxf(y.x, -65504.f), 65504.f); h.x = (_Float16)yc; l.x = (_Float16)(yc - (float)h.x);
-                            yc = fminf(fmaxf(y.y, -65504.f), 65504.f); h.y = (_Float16)yc; l.y = (_Float16)(yc - (float)h.y);
-                            yc = fminf(fmaxf(y.z, -65504.f), 65504.f); h.z = (_Float16)yc; l.z = (_Float16)(yc - (float)h.z);
-                            yc = fminf(fmaxf(y.w, -65504.f), 65504.f); h.w = (_Float16)yc; l.w = (_Float16)(yc - (float)h.w);
-                            _Float16* dst = reinterpret_cast<_Float16*>(a.out + (size_t)m * a.ldo) + (n >> 5) * 64 + (n & 31);
-                            *reinterpret_cast<f16x4*>(dst) = h;
-                            *reinterpret_cast<f16x4*>(dst + 32) = l;
-                        } else {
-                            *reinterpret_cast<f32x4*>(a.out + (size_t)m * a.ldo + n) = y;
-                        }
-                    }
-                }
-            }
-        } else {
-            // ragged output (last_dense: 201 of 256 columns, unaligned rows, optional pre-residual tap)
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int n = nbase + j * 32 + 8 * (r >> 2) + (r & 3);
-                    float x = acc[i][j][r];
-                    if constexpr (PREC == 1) x *= a.ws[n];
-                    x = ((x + cbp[ri.x + n]) + tsp[(ri.y + n) * f_ts]) + fsp[(ri.z + n) * f_fs];
-                    if (m < a.M && n < a.Nreal) {
-                        float y = x;
-                        if (a.id_mode == 1)
-                            y += a.idw[n] * (id_split ? split_load(a.id, (size_t)mc * a.id_ld, n)
-                                                      : a.id[(size_t)mc * a.id_ld + n]);
-                        else if (a.id_mode == 2) y += a.idw[n] * idsv;
-                        if (a.relu) y = fmaxf(y, 0.f);
-                        if (a.aux) a.aux[(size_t)m * a.aux_ld + n] = x;
-                        a.out[(size_t)m * a.ldo + n] = y;
-                    }
-                }
-        }
-    }
+    // ---- epilogue (conv_epilogue.h): transposed through LDS, coalesced on the global side
+    static_assert(conv_epilogue_lds_bytes<BM, BN>() <= (2 * BM * LDA + 2 * BK * BN) * sizeof(float), "epilogue LDS");
+    conv_epilogue<TM, TN, PREC, 256, BM, BN>(a, acc, smem, m0, wm * TM * 32, wn * TN * 32, nt * BN, tid, lane);
 }
 
 template <int BN, int WM, int WN, int PREC, int ABL = 0>
@@ -454,6 +340,10 @@ static void launch_t(const ConvArgs& a, hipStream_t s) {
 double launch_conv_igemm(const ConvArgs& a, hipStream_t s) {
     double k = 0;
     for (int i = 0; i < a.nseg; ++i) k += (double)a.seg[i].nchunks * BK;
+    if (a.variant == 1) {
+        launch_conv_igemm_dma(a, s);
+        return 2.0 * (double)a.M * k * (double)a.Nreal;
+    }
     if (a.prec == 1) {
         static const int abl = [] { const char* e = getenv("NHANS_ABLATE"); return e ? atoi(e) : 0; }();
         if (a.N % 128 == 0) {

@@ -1,0 +1,306 @@
+// Implicit-GEMM convolution, LDS-DMA variant ("v4"): same contract, data layouts, packed weights and
+// epilogue as conv_igemm.hip, different K loop.  Built because the 128-pixel / 4-wave kernel turned
+// out latency-bound in the split-f16 mode: its MFMAs per 32-channel chunk take ~770 cycles per
+// wave while an L2/HBM round trip under load is ~3,000 cycles and its double-buffered LDS allows
+// only one chunk of prefetch (profiles/r01: MFMA busy 37-44 %; removing the MFMAs altogether left
+// 70 % of the run time).
+//
+//   * Workgroup = 8 wavefronts (2 per SIMD), tile = 256 output pixels x BN channels (BN 128 / 64),
+//     wave tile 64 x 64 (BN 128) or 64 x 32 (BN 64): twice the MFMA work per staged byte of B.
+//   * Every operand goes global -> LDS by LDS-DMA (`global_load_lds_dwordx4`): no staging VGPRs,
+//     no ds_write pass, no select for padding -- padded taps read a zero page, resolved once per
+//     filter tap into per-row pointers.
+//   * The LDS-DMA destination is lane-linear, so the A image cannot be padded against bank
+//     conflicts; it is XOR-swizzled instead (16-byte piece p of pixel row r sits at slot p^(r&7)),
+//     applied on the SOURCE address of the DMA and on the ds_read address (2-way worst case).
+//   * 3-stage LDS ring, prefetch distance 2: iteration `it` issues the DMA of chunk it+2, multiplies
+//     chunk it, then waits with a COUNTED `s_waitcnt vmcnt(G)` (G = DMA instructions per chunk) so
+//     that chunk it+1 has landed while chunk it+2 stays in flight across the raw `s_barrier`.
+//     (`__syncthreads()` would drain the queue: hipcc fences LDS-DMA with vmcnt(0).)
+#include "conv_epilogue.h"
+#include <cstdlib>
+
+namespace nhans {
+
+namespace {
+constexpr int DBM = 256, DBK = 32, DSTAGES = 3;
+
+template <int N> __device__ __forceinline__ void wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+}  // namespace
+
+template <int BN, int PREC, int ABL = 0>   // ABL: timing ablations (1: A always from the zero page, 2: B always chunk 0, 4: no epilogue)
+__global__ void __launch_bounds__(512) conv_igemm_dma(const ConvArgs a) {
+    constexpr int WN = 2, WM = 4;                     // wave grid: 4 (pixels) x 2 (channels)
+    constexpr int TM = DBM / WM / 32;                  // 2
+    constexpr int TN = BN / WN / 32;                   // 2 (BN 128) or 1 (BN 64)
+    constexpr int A_STAGE = DBM * 32;                  // floats: 256 rows x 128 B
+    constexpr int B_STAGE = DBK * BN;                  // floats
+    constexpr int STAGE = A_STAGE + B_STAGE;
+    constexpr int GB = BN / 64;                        // B DMA instructions per thread per chunk
+    constexpr int G = 4 + GB;                          // DMA instructions per thread per chunk
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const long long t_start = a.dbg ? (long long)__builtin_amdgcn_s_memtime() : 0;
+
+    // XCD-aware, bijective remap of the linear workgroup id
+    const int ntn = a.N / BN;
+    int L;
+    {
+        const int nblk = gridDim.x, bid = blockIdx.x;
+        const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, idx = bid >> 3;
+        L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int mt = L / ntn, nt = L - mt * ntn;
+    const int m0 = mt * DBM;
+    const int nt0 = nt * (BN / 32);
+
+    // ---- A DMA assignment: instruction j of wave w moves pixel rows j*64 + w*8 .. +7 (8 lanes per
+    // row); lane slot s = lane&7 fetches source piece s ^ (row&7) so that the linear LDS image is
+    // the swizzled one.
+    const int slot = lane & 7;
+    int rb[4], rho[4], rwo[4], spiece[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int row = j * 64 + wave * 8 + (lane >> 3);
+        spiece[j] = (slot ^ (row & 7)) * 4;           // float offset of the source piece
+        const int m = m0 + row;
+        if (m < a.M) {
+            const uint32_t b = fd_div((uint32_t)m, a.fdHoWo);
+            const uint32_t rem = (uint32_t)m - b * a.fdHoWo.d;
+            const uint32_t ho = fd_div(rem, a.fdWo);
+            rb[j] = (int)b; rho[j] = (int)ho; rwo[j] = (int)(rem - ho * a.fdWo.d);
+        } else {
+            rb[j] = -1; rho[j] = 0; rwo[j] = 0;
+        }
+    }
+
+    int64_t roff0, roff1, roff2, roff3;
+    int hi0[4], wi0[4];
+    const float *pa0, *pa1, *pa2, *pa3;
+    int seg = 0, kh = 0, kw = 0, c0 = 0;
+    int sH, sW, sC, sKW, sKH;
+    const float* ssrc;
+
+#define NH_ROW(I, ROFF)                                                                            \
+    if (rb[I] >= 0) {                                                                              \
+        hi0[I] = rho[I] * g.sh - g.pt;                                                             \
+        wi0[I] = rwo[I] * g.sw - g.pl;                                                             \
+        ROFF = (((int64_t)rb[I] * g.H + hi0[I]) * g.W + wi0[I]) * (int64_t)g.C + spiece[I];        \
+    } else {                                                                                       \
+        hi0[I] = -(1 << 28); wi0[I] = 0; ROFF = 0;                                                 \
+    }
+#define NH_TAP_ROW(I, ROFF, PA)                                                                    \
+    PA = (!(ABL & 1) && (unsigned)(hi0[I] + kh) < (unsigned)sH && (unsigned)(wi0[I] + kw) < (unsigned)sW) \
+             ? ssrc + (ROFF + tapoff) : a.zero + spiece[I];
+#define NH_TAP()                                                                                   \
+    {                                                                                              \
+        const int64_t tapoff = (int64_t)(kh * sW + kw) * sC;                                       \
+        NH_TAP_ROW(0, roff0, pa0) NH_TAP_ROW(1, roff1, pa1)                                        \
+        NH_TAP_ROW(2, roff2, pa2) NH_TAP_ROW(3, roff3, pa3)                                        \
+    }
+#define NH_ENTER_SEGMENT(S)                                                                        \
+    {                                                                                              \
+        const ConvSeg& g = a.seg[S];                                                               \
+        sH = g.H; sW = g.W; sC = g.C; sKW = g.KW; sKH = g.KH; ssrc = g.src;                        \
+        NH_ROW(0, roff0) NH_ROW(1, roff1) NH_ROW(2, roff2) NH_ROW(3, roff3)                        \
+        kh = 0; kw = 0; c0 = 0;                                                                    \
+        NH_TAP()                                                                                   \
+    }
+#define NH_ADVANCE_A()                                                                             \
+    {                                                                                              \
+        c0 += DBK;                                                                                 \
+        if (c0 >= sC) {                                                                            \
+            c0 = 0;                                                                                \
+            if (++kw >= sKW) {                                                                     \
+                kw = 0;                                                                            \
+                ++kh;                                                                              \
+            }                                                                                      \
+            if (kh >= sKH) {                                                                       \
+                ++seg;                                                                             \
+                if (seg < a.nseg) NH_ENTER_SEGMENT(seg)                                            \
+            } else NH_TAP()                                                                        \
+        }                                                                                          \
+    }
+
+#define NH_GLDS(SRC, DST)                                                                          \
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(SRC),        \
+                                     (__attribute__((address_space(3))) void*)(DST), 16, 0, 0);
+
+    // issue the DMA of the chunk under the cursor into ring stage ST, then advance the cursor
+    const int n0chunks = a.seg[0].nchunks;
+    const size_t bstride = (size_t)(a.N / 32) * 1024;
+    int lchunk = 0;                                    // index of the next chunk to load
+#define NH_ISSUE(ST)                                                                               \
+    {                                                                                              \
+        float* sa_ = smem + (ST) * STAGE + wave * 8 * 32;                                          \
+        NH_GLDS(pa0 + c0, sa_)                                                                     \
+        NH_GLDS(pa1 + c0, sa_ + 64 * 32)                                                           \
+        NH_GLDS(pa2 + c0, sa_ + 128 * 32)                                                          \
+        NH_GLDS(pa3 + c0, sa_ + 192 * 32)                                                          \
+        const float* bp = ((ABL & 2) ? a.seg[0].wpk                                                \
+                           : lchunk < n0chunks ? a.seg[0].wpk + (size_t)lchunk * bstride           \
+                                             : a.seg[1].wpk + (size_t)(lchunk - n0chunks) * bstride) + \
+                          (size_t)nt0 * 1024;                                                      \
+        float* sb_ = smem + (ST) * STAGE + A_STAGE;                                                \
+        _Pragma("unroll") for (int j = 0; j < GB; ++j)                                             \
+            NH_GLDS(bp + (j * 512 + tid) * 4, sb_ + (j * 512 + wave * 64) * 4)                     \
+        ++lchunk;                                                                                  \
+        NH_ADVANCE_A()                                                                             \
+    }
+
+    // fragment addresses: A row r = wm*64 + t*32 + (lane&31); piece p of that row is at slot p^(r&7)
+    const int g8 = lane >> 5;
+    int aoff[TM];
+#pragma unroll
+    for (int t = 0; t < TM; ++t) aoff[t] = (wm * 64 + t * 32 + (lane & 31)) * 32;
+    const int rsw = lane & 7;                          // (row & 7): tile rows start at multiples of 32
+    const int bcol = A_STAGE + (wn * TN) * 1024 + lane * 4;
+
+#define NH_COMPUTE(ST)                                                                             \
+    {                                                                                              \
+        const float* Sb_ = smem + (ST) * STAGE;                                                    \
+        if constexpr (PREC == 1) {                                                                 \
+            _Pragma("unroll") for (int s = 0; s < 2; ++s) {                                        \
+                f16x8 ah[TM], al[TM], bh[TN], bl[TN];                                              \
+                _Pragma("unroll") for (int t = 0; t < TM; ++t) {                                   \
+                    ah[t] = __builtin_bit_cast(f16x8, *reinterpret_cast<const f32x4*>(Sb_ + aoff[t] + (((2 * s + g8) ^ rsw) * 4)));     \
+                    al[t] = __builtin_bit_cast(f16x8, *reinterpret_cast<const f32x4*>(Sb_ + aoff[t] + (((2 * s + g8 + 4) ^ rsw) * 4))); \
+                }                                                                                  \
+                _Pragma("unroll") for (int j = 0; j < TN; ++j) {                                   \
+                    bh[j] = __builtin_bit_cast(f16x8, *reinterpret_cast<const f32x4*>(Sb_ + bcol + j * 1024 + s * 512));       \
+                    bl[j] = __builtin_bit_cast(f16x8, *reinterpret_cast<const f32x4*>(Sb_ + bcol + j * 1024 + s * 512 + 256)); \
+                }                                                                                  \
+                _Pragma("unroll") for (int t = 0; t < TM; ++t)                                     \
+                    _Pragma("unroll") for (int j = 0; j < TN; ++j) {                               \
+                        acc[t][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[j], al[t], acc[t][j], 0, 0, 0); \
+                        acc[t][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl[j], ah[t], acc[t][j], 0, 0, 0); \
+                        acc[t][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[j], ah[t], acc[t][j], 0, 0, 0); \
+                    }                                                                              \
+            }                                                                                      \
+        } else {                                                                                   \
+            _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                        \
+                f32x4 av[TM], bv[TN];                                                              \
+                _Pragma("unroll") for (int t = 0; t < TM; ++t)                                     \
+                    av[t] = *reinterpret_cast<const f32x4*>(Sb_ + aoff[t] + (((2 * q + g8) ^ rsw) * 4)); \
+                _Pragma("unroll") for (int j = 0; j < TN; ++j)                                     \
+                    bv[j] = *reinterpret_cast<const f32x4*>(Sb_ + bcol + j * 1024 + q * 256);      \
+                _Pragma("unroll") for (int t = 0; t < TM; ++t)                                     \
+                    _Pragma("unroll") for (int j = 0; j < TN; ++j) {                               \
+                        acc[t][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv[j].x, av[t].x, acc[t][j], 0, 0, 0); \
+                        acc[t][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv[j].y, av[t].y, acc[t][j], 0, 0, 0); \
+                        acc[t][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv[j].z, av[t].z, acc[t][j], 0, 0, 0); \
+                        acc[t][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv[j].w, av[t].w, acc[t][j], 0, 0, 0); \
+                    }                                                                              \
+            }                                                                                      \
+        }                                                                                          \
+    }
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int t = 0; t < TM; ++t)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][j][r] = 0.f;
+
+    int total = 0;
+    for (int s = 0; s < a.nseg; ++s) total += a.seg[s].nchunks;
+
+    // prologue: chunks 0 and 1 in flight, wait for chunk 0 only
+    long long t_loop = 0, t_epi = 0;
+    NH_ENTER_SEGMENT(0)
+    NH_ISSUE(0)
+    if (total > 1) {
+        NH_ISSUE(1)
+        wait_vmcnt<G>();
+    } else {
+        wait_vmcnt<0>();
+    }
+    __builtin_amdgcn_s_barrier();
+    if (a.dbg) t_loop = (long long)__builtin_amdgcn_s_memtime();
+
+    int st = 0;                                        // ring stage of chunk `it`
+    for (int it = 0; it < total; ++it) {
+        if (it + 2 < total) {
+            const int st2 = st >= 1 ? st - 1 : st + 2;                 // (st + 2) % 3
+            NH_ISSUE(st2)                                               // chunk it+2 -> stage freed at it-1
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        NH_COMPUTE(st)
+        __builtin_amdgcn_sched_barrier(0);
+        // chunk it+1 must have landed (in every wave) before anyone reads it; chunk it+2 stays in flight
+        if (it + 2 < total) wait_vmcnt<G>(); else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        st = st == 2 ? 0 : st + 1;
+    }
+
+#undef NH_ROW
+#undef NH_TAP_ROW
+#undef NH_TAP
+#undef NH_ENTER_SEGMENT
+#undef NH_ADVANCE_A
+#undef NH_GLDS
+#undef NH_ISSUE
+#undef NH_COMPUTE
+
+    if (a.dbg) t_epi = (long long)__builtin_amdgcn_s_memtime();
+    if constexpr (ABL & 4) {
+        float chk = 0.f;                                 // keep every MFMA alive
+#pragma unroll
+        for (int t = 0; t < TM; ++t)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) chk += acc[t][j][r];
+        if (chk == 123.456f) a.out[0] = chk;
+    } else {
+        static_assert(conv_epilogue_lds_bytes<DBM, BN>() <= (size_t)DSTAGES * STAGE * sizeof(float), "epilogue LDS");
+        conv_epilogue<TM, TN, PREC, 512, DBM, BN>(a, acc, smem, m0, wm * 64, wn * TN * 32, nt * BN, tid, lane);
+    }
+    if (a.dbg) {                                       // dev tool (tools/conv_phase_cycles.py)
+        __syncthreads();
+        if (tid == 0) {
+            long long* d = a.dbg + (size_t)blockIdx.x * 4;
+            d[0] = t_start; d[1] = t_loop; d[2] = t_epi; d[3] = (long long)__builtin_amdgcn_s_memtime();
+        }
+    }
+}
+
+template <int BN, int PREC, int ABL = 0>
+static void launch_dma_t(const ConvArgs& a, hipStream_t s) {
+    constexpr size_t lds = (size_t)DSTAGES * (DBM * 32 + DBK * BN) * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_dma<BN, PREC, ABL>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    const int mtiles = (a.M + DBM - 1) / DBM;
+    const int grid = mtiles * (a.N / BN);
+    hipLaunchKernelGGL((conv_igemm_dma<BN, PREC, ABL>), dim3(grid), dim3(512), lds, s, a);
+}
+
+void launch_conv_igemm_dma(const ConvArgs& a, hipStream_t s) {
+    if (a.prec == 1) {
+        static const int abl = [] { const char* e = getenv("NHANS_ABLATE"); return e ? atoi(e) : 0; }();
+        if (a.N % 128 == 0) {
+            switch (abl) {          // timing experiments only: results are wrong for abl != 0
+                case 1: launch_dma_t<128, 1, 1>(a, s); break;
+                case 2: launch_dma_t<128, 1, 2>(a, s); break;
+                case 3: launch_dma_t<128, 1, 3>(a, s); break;
+                case 4: launch_dma_t<128, 1, 4>(a, s); break;
+                case 7: launch_dma_t<128, 1, 7>(a, s); break;
+                default: launch_dma_t<128, 1>(a, s);
+            }
+        } else launch_dma_t<64, 1>(a, s);
+    } else {
+        if (a.N % 128 == 0) launch_dma_t<128, 0>(a, s); else launch_dma_t<64, 0>(a, s);
+    }
+}
+
+}  // namespace nhans

@@ -109,6 +109,8 @@ struct nhans_ctx {
     std::vector<hipEvent_t> event_pool;
 
     int prec = 0;           // 0: f32 MFMA, 1: split-f16 x3 MFMA (activations in split NHWC)
+    int conv_variant = 0;   // 0: 128-pixel register-staged conv kernel, 1: 256-pixel LDS-DMA kernel
+    long long* dbg = nullptr;   // dev tool: per-workgroup cycle stamps of the last conv launch
 
     const float* A(const std::string& n) const {
         auto it = arr.find(n);
@@ -189,10 +191,11 @@ struct Prof {
 
 void fill_epilogue_defaults(nhans_ctx* c, ConvArgs& a) {
     a.zero = c->A("zero");
-    a.img_clip = nullptr; a.ts = nullptr; a.fs = nullptr; a.id_mode = 0; a.id = nullptr; a.id_ld = 0;
+    a.img_clip = nullptr; a.tf = nullptr; a.id_mode = 0; a.id = nullptr; a.id_ld = 0;
     a.idw = nullptr; a.idH = a.idW = 0; a.idsh = a.idsw = 1; a.relu = 1; a.aux = nullptr; a.aux_ld = 0;
     a.cb_stride = 0;
-    a.prec = c->prec; a.out_split = c->prec; a.id_split = 0; a.ws = nullptr;
+    a.prec = c->prec; a.out_split = c->prec; a.id_split = 0; a.ws = nullptr; a.variant = c->conv_variant;
+    a.dbg = c->dbg;
 }
 
 ConvSeg make_seg(const float* src, const float* wpk, int H, int W, int C, int KH, int KW, int sh, int sw,
@@ -235,7 +238,7 @@ int embed_impl(nhans_ctx* c, const float* ctx_lm, int n, float* emb_out, float* 
                 d.sh = g.sh; d.sw = g.sw;
                 int o; same_pad(g.hin, g.kh, g.sh, &o, &d.pt); same_pad(g.win, g.kw, g.sw, &o, &d.pl);
                 d.Ho = g.hout; d.Wo = g.wout; d.M = nc * g.hout * g.wout; d.out = a1;
-                d.cb = c->A(p + ".c1.cb"); d.cb_stride = 0; d.img_clip = nullptr; d.ts = nullptr; d.fs = nullptr;
+                d.cb = c->A(p + ".c1.cb"); d.cb_stride = 0; d.img_clip = nullptr; d.tf = nullptr;
                 d.relu = 1; d.fdHoWo = make_fastdiv(g.hout * g.wout); d.fdWo = make_fastdiv(g.wout);
                 d.out_split = c->prec;
                 Prof pr(c, s, "direct_conv64");
@@ -331,7 +334,7 @@ float* run_stack_chunk(nhans_ctx* c, const float* logmag, const StackBufs& sb, i
             int o; same_pad(g.hin, g.kh, 1, &o, &d.pt); same_pad(g.win, g.kw, 1, &o, &d.pl);
             d.Ho = g.hout; d.Wo = g.wout; d.M = n * g.hout * g.wout; d.out = a1;
             d.cb = cb1; d.cb_stride = c->cond_cols; d.img_clip = clipmap;
-            d.ts = c->A(p + ".c1.ts"); d.fs = c->A(p + ".c1.fs"); d.relu = 1; d.out_split = c->prec;
+            d.tf = c->A(p + ".c1.tf"); d.relu = 1; d.out_split = c->prec;
             d.fdHoWo = make_fastdiv(g.hout * g.wout); d.fdWo = make_fastdiv(g.wout);
             Prof pr(c, s, "direct_conv64");
             launch_direct_conv64(d, s);
@@ -343,7 +346,7 @@ float* run_stack_chunk(nhans_ctx* c, const float* logmag, const StackBufs& sb, i
             a.seg[0] = make_seg(x, c->WP(p + ".c1.wpk"), g.hin, g.win, g.cin, g.kh, g.kw, g.sh, g.sw, true);
             set_out_geometry(a, n, g.hout, g.wout, g.cout, g.cout, g.cout, a1);
             a.cb = cb1; a.cb_stride = c->cond_cols; a.img_clip = clipmap;
-            a.ts = c->A(p + ".c1.ts"); a.fs = c->A(p + ".c1.fs");
+            a.tf = c->A(p + ".c1.tf");
             a.ws = c->WS(p + ".c1");
             run_conv(c, a, s);
         }
@@ -352,7 +355,7 @@ float* run_stack_chunk(nhans_ctx* c, const float* logmag, const StackBufs& sb, i
         a.nseg = 1;
         a.seg[0] = make_seg(a1, c->WP(p + ".c2.wpk"), g.hout, g.wout, g.cout, g.kh, g.kw, 1, 1, true);
         a.cb = cb2; a.cb_stride = c->cond_cols; a.img_clip = clipmap;
-        a.ts = c->A(p + ".c2.ts"); a.fs = c->A(p + ".c2.fs");
+        a.tf = c->A(p + ".c2.tf");
         a.idw = c->A(p + ".c2.idw");
         a.ws = c->WS(p + ".c2");
         float* out;
@@ -568,8 +571,7 @@ int nhans_create(int model_kind, const void* blob, size_t nbytes, int device_id,
         if (b > 0 && g.cin != g.cout) need.push_back({p + ".c2.wpk_t", (size_t)g.cin * g.cout});
         need.push_back({p + ".c2.idw", (size_t)g.cout});
         for (const char* cv : {".c1", ".c2"}) {
-            need.push_back({p + cv + ".ts", (size_t)g.hout * g.cout});
-            need.push_back({p + cv + ".fs", (size_t)g.wout * g.cout});
+            need.push_back({p + cv + ".tf", (size_t)g.hout * g.wout * g.cout});
         }
     }
     for (const auto& kv : need) {
@@ -603,6 +605,11 @@ int nhans_set_option(nhans_ctx* c, const char* key, int64_t value) {
     if (k == "frames_per_chunk") { if (value < 1) return fail(NHANS_EINVAL, "frames_per_chunk < 1"); c->frames_per_chunk = value; }
     else if (k == "contexts_per_chunk") { if (value < 1) return fail(NHANS_EINVAL, "contexts_per_chunk < 1"); c->contexts_per_chunk = (int)value; }
     else if (k == "profile") c->profile = value != 0;
+    else if (k == "debug_cycles_ptr") c->dbg = reinterpret_cast<long long*>(static_cast<intptr_t>(value));
+    else if (k == "conv_variant") {
+        if (value != 0 && value != 1) return fail(NHANS_EINVAL, "conv_variant must be 0 or 1");
+        c->conv_variant = (int)value;
+    }
     else if (k == "precision") {
         if (value != 0 && value != 1) return fail(NHANS_EINVAL, "precision must be 0 (f32) or 1 (f16x3)");
         if (value == 1 && !c->A("head.dense.wpk_h"))

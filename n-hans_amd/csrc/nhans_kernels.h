@@ -47,7 +47,7 @@ struct ConvArgs {
     int Nreal;          // stored channels
     int ldo;            // out row stride
     float* out;
-    // epilogue: v = acc + cb[clip(b)*cb_stride + n] + ts[ho*N+n] + fs[wo*N+n]
+    // epilogue: v = acc + cb[clip(b)*cb_stride + n] + tf[(ho*Wo+wo)*N + n]
     //           aux[m*aux_ld+n] = v (optional)
     //           v += idw[n]*id[m*id_ld+n]                       (id_mode 1: same-shape tensor)
     //           v += idw[n]*ids[(b*idH + ho*idsh)*idW + wo*idsw] (id_mode 2: 1-channel image)
@@ -55,8 +55,7 @@ struct ConvArgs {
     const float* cb;
     int cb_stride;
     const int* img_clip;   // nullable -> clip 0
-    const float* ts;       // nullable
-    const float* fs;       // nullable
+    const float* tf;       // nullable: time+frequency position table [Ho*Wo, N]
     int id_mode;
     const float* id;
     int id_ld;
@@ -70,11 +69,14 @@ struct ConvArgs {
     int out_split;         // write `out` as split NHWC (ldo = N words per pixel) instead of f32
     int id_split;          // id_mode 1 tensor is split NHWC
     const float* ws;       // prec 1: per-channel power-of-two that undoes the weight pre-scaling
+    int variant;           // 0: 128-pixel / 4-wave register-staged kernel, 1: 256-pixel / 8-wave LDS-DMA kernel
+    long long* dbg;        // optional (dev tool): 4 s_memtime stamps per workgroup [start, loop, epilogue, end]
     FastDiv fdHoWo, fdWo;
 };
 
 // returns algorithmic FLOPs of the launch (2*M*K*Nreal)
 double launch_conv_igemm(const ConvArgs& a, hipStream_t s);
+void launch_conv_igemm_dma(const ConvArgs& a, hipStream_t s);   // conv_igemm_dma.hip
 
 // ---------------------------------------------------------------------------------------------
 // Small kernels (aux_kernels.hip)
@@ -87,8 +89,7 @@ struct DirectArgs {     // convolution of a 1-channel image into 64 channels, sa
     const float* cb;
     int cb_stride;
     const int* img_clip;
-    const float* ts;    // [Ho,64] nullable
-    const float* fs;    // [Wo,64] nullable
+    const float* tf;    // [Ho*Wo,64] nullable
     int relu;
     int out_split;      // write split NHWC (hi/lo f16) instead of f32
     FastDiv fdHoWo, fdWo;

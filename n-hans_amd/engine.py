@@ -40,6 +40,8 @@ class Engine:
         if frames_per_chunk:
             self.set_option("frames_per_chunk", frames_per_chunk)
         self.set_precision(precision)
+        if "NHANS_CONV_VARIANT" in os.environ:
+            self.set_option("conv_variant", int(os.environ["NHANS_CONV_VARIANT"]))
 
     def set_precision(self, precision):
         """'f32': exact f32 matrix-core path.  'f16x3': split-f16 (hi+lo, three products) on the f16

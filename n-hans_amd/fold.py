@@ -169,8 +169,10 @@ def fold_arrays(W, kind, split_f16=True):
             emit(p + ".c2", [(p + ".c2.wpk", w2)])
         for cv, sc, sh, bias in ((1, s1, h1, 0.0), (2, sa, ha, extra_bias)):
             q = "%s_conv%d" % (s, cv)
-            out["%s.c%d.ts" % (p, cv)] = (_cont_embed(W, g["hout"], q + "_temb") * sc).reshape(-1)
-            out["%s.c%d.fs" % (p, cv)] = (_cont_embed(W, g["wout"], q + "_femb") * sc).reshape(-1)
+            # time + frequency position terms in one [Ho*Wo, C] table (one coalesced read per output)
+            tt = _cont_embed(W, g["hout"], q + "_temb") * sc
+            ff = _cont_embed(W, g["wout"], q + "_femb") * sc
+            out["%s.c%d.tf" % (p, cv)] = (tt[:, None, :] + ff[None, :, :]).reshape(-1)
             cond_w.append(np.concatenate([w64(q + ea + "/w"), w64(q + eb + "/w")], 0) * sc)
             cond_b.append(sc * (w64(q + ea + "/b").reshape(-1) + w64(q + eb + "/b").reshape(-1) + bias) + sh)
     out["cond.w"] = np.concatenate(cond_w, 1).reshape(-1)       # [1024, 3840]

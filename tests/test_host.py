@@ -86,7 +86,7 @@ def test_fold_blob_structure(weights_denoiser):
     assert arrs["m0.c1.w"].size == 16 * 64 and arrs["t0.c1.w"].size == 32 * 64
     assert arrs["m2.c2.wpk_t"].size == 64 * 128 and "m1.c2.wpk_t" not in arrs
     assert arrs["head.dense.wpk"].size == 13312 * 256
-    assert arrs["m0.c1.ts"].size == 35 * 64 and arrs["m7.c2.fs"].size == 26 * 512
+    assert arrs["m0.c1.tf"].size == 35 * 201 * 64 and arrs["m7.c2.tf"].size == 5 * 26 * 512
     # BN scale really is folded: conv1 weights of block 1 equal w * gamma/sqrt(var+eps)
     W = weights_denoiser
     sc = (W["resblock1_2_conv1/gamma"].astype(np.float64) /
