@@ -30,7 +30,7 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
 }
 }  // namespace
 
-template <int BN, int PREC, int ABL = 0>   // ABL: timing ablations (1: A always from the zero page, 2: B always chunk 0, 4: no epilogue)
+template <int BN, int PREC, int ABL = 0, int PINGPONG = 0>   // ABL: timing ablations (1: A from the zero page, 2: B always chunk 0, 4: no epilogue)
 __global__ void __launch_bounds__(512) conv_igemm_dma(const ConvArgs a) {
     constexpr int WN = 2, WM = 4;                     // wave grid: 4 (pixels) x 2 (channels)
     constexpr int TM = DBM / WM / 32;                  // 2
@@ -161,43 +161,46 @@ __global__ void __launch_bounds__(512) conv_igemm_dma(const ConvArgs a) {
     const int rsw = lane & 7;                          // (row & 7): tile rows start at multiples of 32
     const int bcol = A_STAGE + (wn * TN) * 1024 + lane * 4;
 
-#define NH_COMPUTE(ST)                                                                             \
+    // MFMA operands of one whole chunk live in registers between the two phases
+    constexpr int KS = PREC == 1 ? 2 : 4;              // k-steps per chunk (16 k each / 8 k each)
+    f32x4 fa_hi[KS][TM], fa_lo[PREC == 1 ? KS : 1][TM], fb_hi[KS][TN], fb_lo[PREC == 1 ? KS : 1][TN];
+#define NH_READ_FRAGS(ST)                                                                          \
     {                                                                                              \
         const float* Sb_ = smem + (ST) * STAGE;                                                    \
-        if constexpr (PREC == 1) {                                                                 \
-            _Pragma("unroll") for (int s = 0; s < 2; ++s) {                                        \
-                f16x8 ah[TM], al[TM], bh[TN], bl[TN];                                              \
-                _Pragma("unroll") for (int t = 0; t < TM; ++t) {                                   \
-                    ah[t] = __builtin_bit_cast(f16x8, *reinterpret_cast<const f32x4*>(Sb_ + aoff[t] + (((2 * s + g8) ^ rsw) * 4)));     \
-                    al[t] = __builtin_bit_cast(f16x8, *reinterpret_cast<const f32x4*>(Sb_ + aoff[t] + (((2 * s + g8 + 4) ^ rsw) * 4))); \
-                }                                                                                  \
-                _Pragma("unroll") for (int j = 0; j < TN; ++j) {                                   \
-                    bh[j] = __builtin_bit_cast(f16x8, *reinterpret_cast<const f32x4*>(Sb_ + bcol + j * 1024 + s * 512));       \
-                    bl[j] = __builtin_bit_cast(f16x8, *reinterpret_cast<const f32x4*>(Sb_ + bcol + j * 1024 + s * 512 + 256)); \
-                }                                                                                  \
-                _Pragma("unroll") for (int t = 0; t < TM; ++t)                                     \
-                    _Pragma("unroll") for (int j = 0; j < TN; ++j) {                               \
-                        acc[t][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[j], al[t], acc[t][j], 0, 0, 0); \
-                        acc[t][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl[j], ah[t], acc[t][j], 0, 0, 0); \
-                        acc[t][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[j], ah[t], acc[t][j], 0, 0, 0); \
-                    }                                                                              \
+        _Pragma("unroll") for (int s = 0; s < KS; ++s) {                                           \
+            _Pragma("unroll") for (int t = 0; t < TM; ++t) {                                       \
+                fa_hi[s][t] = *reinterpret_cast<const f32x4*>(Sb_ + aoff[t] + (((2 * s + g8) ^ rsw) * 4)); \
+                if constexpr (PREC == 1)                                                           \
+                    fa_lo[s][t] = *reinterpret_cast<const f32x4*>(Sb_ + aoff[t] + (((2 * s + g8 + 4) ^ rsw) * 4)); \
             }                                                                                      \
-        } else {                                                                                   \
-            _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                        \
-                f32x4 av[TM], bv[TN];                                                              \
-                _Pragma("unroll") for (int t = 0; t < TM; ++t)                                     \
-                    av[t] = *reinterpret_cast<const f32x4*>(Sb_ + aoff[t] + (((2 * q + g8) ^ rsw) * 4)); \
-                _Pragma("unroll") for (int j = 0; j < TN; ++j)                                     \
-                    bv[j] = *reinterpret_cast<const f32x4*>(Sb_ + bcol + j * 1024 + q * 256);      \
-                _Pragma("unroll") for (int t = 0; t < TM; ++t)                                     \
-                    _Pragma("unroll") for (int j = 0; j < TN; ++j) {                               \
-                        acc[t][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv[j].x, av[t].x, acc[t][j], 0, 0, 0); \
-                        acc[t][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv[j].y, av[t].y, acc[t][j], 0, 0, 0); \
-                        acc[t][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv[j].z, av[t].z, acc[t][j], 0, 0, 0); \
-                        acc[t][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv[j].w, av[t].w, acc[t][j], 0, 0, 0); \
-                    }                                                                              \
+            _Pragma("unroll") for (int j = 0; j < TN; ++j) {                                       \
+                if constexpr (PREC == 1) {                                                         \
+                    fb_hi[s][j] = *reinterpret_cast<const f32x4*>(Sb_ + bcol + j * 1024 + s * 512);       \
+                    fb_lo[s][j] = *reinterpret_cast<const f32x4*>(Sb_ + bcol + j * 1024 + s * 512 + 256); \
+                } else {                                                                           \
+                    fb_hi[s][j] = *reinterpret_cast<const f32x4*>(Sb_ + bcol + j * 1024 + s * 256); \
+                }                                                                                  \
             }                                                                                      \
         }                                                                                          \
+    }
+#define NH_MFMA_FRAGS()                                                                            \
+    {                                                                                              \
+        _Pragma("unroll") for (int s = 0; s < KS; ++s)                                             \
+            _Pragma("unroll") for (int t = 0; t < TM; ++t)                                         \
+                _Pragma("unroll") for (int j = 0; j < TN; ++j) {                                   \
+                    if constexpr (PREC == 1) {                                                     \
+                        const f16x8 ah_ = __builtin_bit_cast(f16x8, fa_hi[s][t]), al_ = __builtin_bit_cast(f16x8, fa_lo[s][t]); \
+                        const f16x8 bh_ = __builtin_bit_cast(f16x8, fb_hi[s][j]), bl_ = __builtin_bit_cast(f16x8, fb_lo[s][j]); \
+                        acc[t][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh_, al_, acc[t][j], 0, 0, 0); \
+                        acc[t][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl_, ah_, acc[t][j], 0, 0, 0); \
+                        acc[t][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh_, ah_, acc[t][j], 0, 0, 0); \
+                    } else {                                                                       \
+                        acc[t][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb_hi[s][j].x, fa_hi[s][t].x, acc[t][j], 0, 0, 0); \
+                        acc[t][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb_hi[s][j].y, fa_hi[s][t].y, acc[t][j], 0, 0, 0); \
+                        acc[t][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb_hi[s][j].z, fa_hi[s][t].z, acc[t][j], 0, 0, 0); \
+                        acc[t][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb_hi[s][j].w, fa_hi[s][t].w, acc[t][j], 0, 0, 0); \
+                    }                                                                              \
+                }                                                                                  \
     }
 
     f32x16 acc[TM][TN];
@@ -224,19 +227,66 @@ __global__ void __launch_bounds__(512) conv_igemm_dma(const ConvArgs a) {
     __builtin_amdgcn_s_barrier();
     if (a.dbg) t_loop = (long long)__builtin_amdgcn_s_memtime();
 
-    int st = 0;                                        // ring stage of chunk `it`
-    for (int it = 0; it < total; ++it) {
-        if (it + 2 < total) {
-            const int st2 = st >= 1 ? st - 1 : st + 2;                 // (st + 2) % 3
-            NH_ISSUE(st2)                                               // chunk it+2 -> stage freed at it-1
+    if constexpr (PINGPONG) {
+        // Ping-pong: waves w and w+4 share a SIMD.  Each iteration has two phases separated by
+        // workgroup barriers -- P1: issue the DMA share of chunk it+2, read every MFMA fragment of
+        // chunk it from LDS into registers, counted wait for the own share of chunk it+1; P2: the
+        // 24 (12) MFMAs from registers.  Waves 4-7 pass one extra barrier up front, so on every SIMD
+        // one wave is always in P2 (matrix pipe) while the other is in P1 (memory / LDS): without the
+        // stagger both run the same phase at the same time and the matrix pipe idles during P1.
+        // Hazards (k = barrier index; group A runs P1(it) at k=2it, group B at k=2it+1):
+        //   chunk c is read at k=2c (A), 2c+1 (B); its stage is rewritten for chunk c+3 from k=2c+2
+        //   on, and every wave drains its ds_reads (lgkmcnt 0) before leaving P1;
+        //   the shares of chunk c are issued at k=2c-4 (A), 2c-3 (B) and waited for at k=2c-2 (A),
+        //   2c-1 (B), both before the barrier that precedes the first read.
+        const bool grp_b = wave >= 4;
+        if (grp_b) __builtin_amdgcn_s_barrier();
+        int st = 0;
+        for (int it = 0; it < total; ++it) {
+            if (it + 2 < total) {
+                const int st2 = st >= 1 ? st - 1 : st + 2;             // (st + 2) % 3
+                NH_ISSUE(st2)
+            }
+            NH_READ_FRAGS(st)
+            if (it + 2 < total) wait_vmcnt<G>(); else wait_vmcnt<0>();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (ABL & 32) __builtin_amdgcn_s_setprio(1);
+            NH_MFMA_FRAGS()
+            if constexpr (ABL & 32) __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            st = st == 2 ? 0 : st + 1;
         }
-        __builtin_amdgcn_sched_barrier(0);
-        NH_COMPUTE(st)
-        __builtin_amdgcn_sched_barrier(0);
-        // chunk it+1 must have landed (in every wave) before anyone reads it; chunk it+2 stays in flight
-        if (it + 2 < total) wait_vmcnt<G>(); else wait_vmcnt<0>();
-        __builtin_amdgcn_s_barrier();
-        st = st == 2 ? 0 : st + 1;
+        if (!grp_b) __builtin_amdgcn_s_barrier();
+    } else {
+        int st = 0;                                    // ring stage of chunk `it`
+        long long ph0 = 0, ph1 = 0, ph2 = 0, ph3 = 0, tq = 0;          // dev tool: in-loop phase cycles
+        for (int it = 0; it < total; ++it) {
+            if (a.dbg) tq = (long long)__builtin_amdgcn_s_memtime();
+            if (it + 2 < total) {
+                const int st2 = st >= 1 ? st - 1 : st + 2;             // (st + 2) % 3
+                NH_ISSUE(st2)                                           // chunk it+2 -> stage freed at it-1
+            }
+            if (a.dbg) { __builtin_amdgcn_sched_barrier(0); const long long t = (long long)__builtin_amdgcn_s_memtime(); ph0 += t - tq; tq = t; }
+            NH_READ_FRAGS(st)
+            if (a.dbg) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_sched_barrier(0); const long long t = (long long)__builtin_amdgcn_s_memtime(); ph1 += t - tq; tq = t; }
+            NH_MFMA_FRAGS()
+            __builtin_amdgcn_sched_barrier(0);
+            if (a.dbg) { const long long t = (long long)__builtin_amdgcn_s_memtime(); ph2 += t - tq; tq = t; }
+            // chunk it+1 must have landed (in every wave) before anyone reads it; chunk it+2 stays in flight
+            if (it + 2 < total) wait_vmcnt<G>(); else wait_vmcnt<0>();
+            __builtin_amdgcn_s_barrier();
+            if (a.dbg) { const long long t = (long long)__builtin_amdgcn_s_memtime(); ph3 += t - tq; }
+            st = st == 2 ? 0 : st + 1;
+        }
+        if (a.dbg && tid == 0) {
+            long long* d = a.dbg + (size_t)(4 << 20) + (size_t)blockIdx.x * 4;
+            d[0] = ph0; d[1] = ph1; d[2] = ph2; d[3] = ph3;
+        }
     }
 
 #undef NH_ROW
@@ -246,7 +296,8 @@ __global__ void __launch_bounds__(512) conv_igemm_dma(const ConvArgs a) {
 #undef NH_ADVANCE_A
 #undef NH_GLDS
 #undef NH_ISSUE
-#undef NH_COMPUTE
+#undef NH_READ_FRAGS
+#undef NH_MFMA_FRAGS
 
     if (a.dbg) t_epi = (long long)__builtin_amdgcn_s_memtime();
     if constexpr (ABL & 4) {
@@ -271,18 +322,18 @@ __global__ void __launch_bounds__(512) conv_igemm_dma(const ConvArgs a) {
     }
 }
 
-template <int BN, int PREC, int ABL = 0>
+template <int BN, int PREC, int ABL = 0, int PINGPONG = 0>
 static void launch_dma_t(const ConvArgs& a, hipStream_t s) {
     constexpr size_t lds = (size_t)DSTAGES * (DBM * 32 + DBK * BN) * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_dma<BN, PREC, ABL>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_dma<BN, PREC, ABL, PINGPONG>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
     const int mtiles = (a.M + DBM - 1) / DBM;
     const int grid = mtiles * (a.N / BN);
-    hipLaunchKernelGGL((conv_igemm_dma<BN, PREC, ABL>), dim3(grid), dim3(512), lds, s, a);
+    hipLaunchKernelGGL((conv_igemm_dma<BN, PREC, ABL, PINGPONG>), dim3(grid), dim3(512), lds, s, a);
 }
 
 void launch_conv_igemm_dma(const ConvArgs& a, hipStream_t s) {
@@ -295,9 +346,12 @@ void launch_conv_igemm_dma(const ConvArgs& a, hipStream_t s) {
                 case 3: launch_dma_t<128, 1, 3>(a, s); break;
                 case 4: launch_dma_t<128, 1, 4>(a, s); break;
                 case 7: launch_dma_t<128, 1, 7>(a, s); break;
+                case 8: launch_dma_t<128, 1, 8>(a, s); break;
+                case 16: launch_dma_t<128, 1, 0, 1>(a, s); break;      // ping-pong phase stagger (slower, kept for reference)
                 default: launch_dma_t<128, 1>(a, s);
             }
-        } else launch_dma_t<64, 1>(a, s);
+        } else if (abl == 16) launch_dma_t<64, 1, 0, 1>(a, s);
+        else launch_dma_t<64, 1>(a, s);
     } else {
         if (a.N % 128 == 0) launch_dma_t<128, 0>(a, s); else launch_dma_t<64, 0>(a, s);
     }

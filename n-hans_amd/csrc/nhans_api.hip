@@ -109,7 +109,8 @@ struct nhans_ctx {
     std::vector<hipEvent_t> event_pool;
 
     int prec = 0;           // 0: f32 MFMA, 1: split-f16 x3 MFMA (activations in split NHWC)
-    int conv_variant = 0;   // 0: 128-pixel register-staged conv kernel, 1: 256-pixel LDS-DMA kernel
+    int conv_variant = -1;  // 0: 128-pixel register-staged conv kernel, 1: 256-pixel LDS-DMA kernel,
+                            // -1: automatic (measured best: LDS-DMA for split-f16, register-staged for f32)
     long long* dbg = nullptr;   // dev tool: per-workgroup cycle stamps of the last conv launch
 
     const float* A(const std::string& n) const {
@@ -194,7 +195,8 @@ void fill_epilogue_defaults(nhans_ctx* c, ConvArgs& a) {
     a.img_clip = nullptr; a.tf = nullptr; a.id_mode = 0; a.id = nullptr; a.id_ld = 0;
     a.idw = nullptr; a.idH = a.idW = 0; a.idsh = a.idsw = 1; a.relu = 1; a.aux = nullptr; a.aux_ld = 0;
     a.cb_stride = 0;
-    a.prec = c->prec; a.out_split = c->prec; a.id_split = 0; a.ws = nullptr; a.variant = c->conv_variant;
+    a.prec = c->prec; a.out_split = c->prec; a.id_split = 0; a.ws = nullptr;
+    a.variant = c->conv_variant >= 0 ? c->conv_variant : (c->prec == 1 ? 1 : 0);
     a.dbg = c->dbg;
 }
 
@@ -607,7 +609,7 @@ int nhans_set_option(nhans_ctx* c, const char* key, int64_t value) {
     else if (k == "profile") c->profile = value != 0;
     else if (k == "debug_cycles_ptr") c->dbg = reinterpret_cast<long long*>(static_cast<intptr_t>(value));
     else if (k == "conv_variant") {
-        if (value != 0 && value != 1) return fail(NHANS_EINVAL, "conv_variant must be 0 or 1");
+        if (value < -1 || value > 1) return fail(NHANS_EINVAL, "conv_variant must be -1 (auto), 0 or 1");
         c->conv_variant = (int)value;
     }
     else if (k == "precision") {

@@ -22,7 +22,7 @@ def main():
     mix = trim_to_frames(normalise(synth.mixture(0, 10.0)))
     lm, _ = eng.stft_features(torch.from_numpy(mix).cuda(), [0, len(mix)])
     ea = torch.zeros(1, 512, device="cuda")
-    dbg = torch.zeros(4 * (1 << 20), dtype=torch.int64, device="cuda")
+    dbg = torch.zeros(8 * (1 << 20), dtype=torch.int64, device="cuda")
     eng.set_option("debug_cycles_ptr", dbg.data_ptr())
     eng.set_option("frames_per_chunk", frames)
     for _ in range(2):
@@ -33,7 +33,11 @@ def main():
     g = spec.main_geometry()[block]
     bn = 128 if g["cout"] >= 128 else 64
     nblk = -(-(frames * g["hout"] * g["wout"]) // 256) * (g["cout"] // bn)
-    d = dbg.cpu().numpy().reshape(-1, 4)[:nblk]          # the last launch is this block's conv2
+    raw = dbg.cpu().numpy()
+    d = raw[:4 << 20].reshape(-1, 4)[:nblk]               # the last launch is this block's conv2
+    ph = raw[4 << 20:].reshape(-1, 4)[:nblk]
+    nch = g["kh"] * g["kw"] * g["cout"] // 32 + (g["cin"] // 32 if g["cin"] not in (1, g["cout"]) else 0)
+    print("in-loop cycles per chunk (wave 0): issue %.0f | frag reads %.0f | mfma issue %.0f | dma wait + barrier %.0f" % tuple(ph.mean(0) / nch))
     pro, loop, epi = d[:, 1] - d[:, 0], d[:, 2] - d[:, 1], d[:, 3] - d[:, 2]
     span = d[:, 3].max() - d[:, 0].min()
     print("block %d conv2: %d workgroups; s_memtime ticks (100 MHz) median pro/loop/epi = %d / %d / %d ; "
