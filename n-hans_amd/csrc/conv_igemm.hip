@@ -340,8 +340,9 @@ static void launch_t(const ConvArgs& a, hipStream_t s) {
 double launch_conv_igemm(const ConvArgs& a, hipStream_t s) {
     double k = 0;
     for (int i = 0; i < a.nseg; ++i) k += (double)a.seg[i].nchunks * BK;
-    if (a.variant == 1) {
-        launch_conv_igemm_dma(a, s);
+    if (a.variant >= 1) {
+        if (a.variant == 2 && conv_igemm_halo_eligible(a)) launch_conv_igemm_halo(a, s);
+        else launch_conv_igemm_dma(a, s);
         return 2.0 * (double)a.M * k * (double)a.Nreal;
     }
     if (a.prec == 1) {

@@ -609,7 +609,7 @@ int nhans_set_option(nhans_ctx* c, const char* key, int64_t value) {
     else if (k == "profile") c->profile = value != 0;
     else if (k == "debug_cycles_ptr") c->dbg = reinterpret_cast<long long*>(static_cast<intptr_t>(value));
     else if (k == "conv_variant") {
-        if (value < -1 || value > 1) return fail(NHANS_EINVAL, "conv_variant must be -1 (auto), 0 or 1");
+        if (value < -1 || value > 2) return fail(NHANS_EINVAL, "conv_variant must be -1 (auto), 0, 1 or 2");
         c->conv_variant = (int)value;
     }
     else if (k == "precision") {

@@ -69,14 +69,18 @@ struct ConvArgs {
     int out_split;         // write `out` as split NHWC (ldo = N words per pixel) instead of f32
     int id_split;          // id_mode 1 tensor is split NHWC
     const float* ws;       // prec 1: per-channel power-of-two that undoes the weight pre-scaling
-    int variant;           // 0: 128-pixel / 4-wave register-staged kernel, 1: 256-pixel / 8-wave LDS-DMA kernel
+    int variant;           // 0: 128-pixel / 4-wave register-staged kernel, 1: 256-pixel / 8-wave LDS-DMA kernel,
+                           // 2: LDS-DMA kernel with halo reuse across the KW taps where the conv allows it
     long long* dbg;        // optional (dev tool): 4 s_memtime stamps per workgroup [start, loop, epilogue, end]
     FastDiv fdHoWo, fdWo;
+    FastDiv fdWP;          // Wo + KW - 1 (filled in by launch_conv_igemm_halo)
 };
 
 // returns algorithmic FLOPs of the launch (2*M*K*Nreal)
 double launch_conv_igemm(const ConvArgs& a, hipStream_t s);
 void launch_conv_igemm_dma(const ConvArgs& a, hipStream_t s);   // conv_igemm_dma.hip
+bool conv_igemm_halo_eligible(const ConvArgs& a);               // conv_igemm_halo.hip
+void launch_conv_igemm_halo(const ConvArgs& a, hipStream_t s);
 
 // ---------------------------------------------------------------------------------------------
 // Small kernels (aux_kernels.hip)
