@@ -113,18 +113,18 @@ __global__ void __launch_bounds__(512) conv_igemm_dma(const ConvArgs a) {
     }
 #define NH_ADVANCE_A()                                                                             \
     {                                                                                              \
-        c0 += DBK;                                                                                 \
-        if (c0 >= sC) {                                                                            \
-            c0 = 0;                                                                                \
-            if (++kw >= sKW) {                                                                     \
-                kw = 0;                                                                            \
+        if (++kw >= sKW) {            /* K order (fold.py kmat): row, chunk, column, channel */    \
+            kw = 0;                                                                                \
+            c0 += DBK;                                                                             \
+            if (c0 >= sC) {                                                                        \
+                c0 = 0;                                                                            \
                 ++kh;                                                                              \
             }                                                                                      \
-            if (kh >= sKH) {                                                                       \
-                ++seg;                                                                             \
-                if (seg < a.nseg) NH_ENTER_SEGMENT(seg)                                            \
-            } else NH_TAP()                                                                        \
         }                                                                                          \
+        if (kh >= sKH) {                                                                           \
+            ++seg;                                                                                 \
+            if (seg < a.nseg) NH_ENTER_SEGMENT(seg)                                                \
+        } else NH_TAP()                                                                            \
     }
 
 #define NH_GLDS(SRC, DST)                                                                          \

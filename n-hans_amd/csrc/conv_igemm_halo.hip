@@ -29,6 +29,7 @@
 // column stride 1 and SAME padding (Wo == W), segment 1 (if any) has KW == 1, and the halo image of
 // any 256-pixel run fits 320 rows.
 #include "conv_epilogue.h"
+#include <cstdlib>
 
 namespace nhans {
 
@@ -41,9 +42,10 @@ constexpr int BST = 4;        // weight ring stages
 template <int N> __device__ __forceinline__ void halo_wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
+
 }  // namespace
 
-template <int BN, int PREC>
+template <int BN, int PREC, int PP = 1, int DBG = 0>   // PP: ping-pong K loop; DBG: dev tool, per-workgroup cycle stamps (tools/conv_phase_cycles.py)
 __global__ void __launch_bounds__(512) conv_igemm_halo(const ConvArgs a) {
     constexpr int TM = 2;                              // wave grid 4 (pixels) x 2 (channels), wave tile 64 x BN/2
     constexpr int TN = BN / 64;
@@ -75,7 +77,10 @@ __global__ void __launch_bounds__(512) conv_igemm_halo(const ConvArgs a) {
     const int nrows_all = a.M / Wo;                    // B * Ho
 
     // ---- activation DMA assignment: instruction d of wave w fills LDS rows d*64 + w*8 .. +7, 8 lanes
-    // per row; lane slot s = lane&7 fetches source piece s ^ (row&7) (XOR swizzle applied at the source).
+    // per row; lane slot s = lane&7 fetches source piece s ^ ((row>>1)&7) (XOR swizzle applied at the
+    // source).  A 256-B bank row holds two 128-B pixel rows, so the 16-byte bank slot of (row, piece) is
+    // (row&1)*8 + piece^f(row); a ds_read_b128 lane group covers rows {r..r+3, r+12..r+15, r+20..r+27}
+    // of one fragment, and f = (row>>1)&7 is the choice that makes those 16 slots distinct for any r.
     // Per row: element offset of its pixel for kh = 0 / chunk 0 (the launcher checks that tensors stay
     // below 2^31 elements) and the input row hi0 of kh = 0, or a sentinel for padding / unused rows.
     const int slot = lane & 7;
@@ -87,7 +92,7 @@ __global__ void __launch_bounds__(512) conv_igemm_halo(const ConvArgs a) {
 #define NH_MAP_ROW(D, POFF, HOV)                                                                   \
     {                                                                                              \
         const int j = (D) * 64 + wave * 8 + (lane >> 3);                                           \
-        const int sp = (slot ^ (j & 7)) * 4;                                                       \
+        const int sp = (slot ^ ((j >> 1) & 7)) * 4;                                                \
         int Rg, wi;                                                                                \
         bool ok;                                                                                   \
         if (g.KW > 1) {                                                                            \
@@ -154,6 +159,9 @@ __global__ void __launch_bounds__(512) conv_igemm_halo(const ConvArgs a) {
         NH_GLDS(p2_, sa_ + 128 * 32)                                                               \
         NH_GLDS(p3_, sa_ + 192 * 32)                                                               \
         NH_GLDS(p4_, sa_ + 256 * 32)                                                               \
+    }
+#define NH_ADVANCE_A()                                                                             \
+    {                                                                                              \
         ++supA;                                                                                    \
         if (++ccA >= (segA ? CC1 : CC0)) {                                                         \
             ccA = 0;                                                                               \
@@ -167,23 +175,19 @@ __global__ void __launch_bounds__(512) conv_igemm_halo(const ConvArgs a) {
         }                                                                                          \
     }
 
-    // ---- weight cursor: next tap to stage, in the order (segment, kh, chunk, kw)
-    int segB = 0, khB = 0, ccB = 0, kwB = 0, tapB = 0;
-    const float* bp_ = a.seg[0].wpk + (size_t)nt0 * 1024;
+    // ---- weight cursor: the packed weights are stored in the order the taps are walked (fold.py
+    // kmat), so the next tap is the next `bstride` floats; one jump to the transform's array, and a
+    // stall on the last chunk for the dummy loads past the end.  (Kept branch-free: the DMAs must sit
+    // in one basic block with the MFMAs they are interleaved with.)
+    const int ntap0 = nsup0 * KW0;
+    int tapB = 0;
+    const float* bp_ = a.seg[0].wpk + (size_t)nt0 * 1024 - bstride;
+    const float* const wpk1 = (nseg > 1 ? a.seg[1].wpk : a.seg[0].wpk) + (size_t)nt0 * 1024;
 #define NH_ISSUE_B(ST)                                                                             \
     {                                                                                              \
-        if (tapB < total) {                                                                        \
-            const int chunk_ = segB ? khB * CC1 + ccB : (khB * KW0 + kwB) * CC0 + ccB;             \
-            bp_ = (segB ? a.seg[1].wpk : a.seg[0].wpk) + (size_t)chunk_ * bstride + (size_t)nt0 * 1024; \
-            ++tapB;                                                                                \
-            if (++kwB >= (segB ? 1 : KW0)) {                                                       \
-                kwB = 0;                                                                           \
-                if (++ccB >= (segB ? CC1 : CC0)) {                                                 \
-                    ccB = 0;                                                                       \
-                    if (++khB >= (segB ? KH1 : KH0)) { khB = 0; segB = 1; }                        \
-                }                                                                                  \
-            }                                                                                      \
-        }                                                                                          \
+        const float* nx_ = tapB == ntap0 ? wpk1 : bp_ + bstride;                                   \
+        bp_ = tapB < total ? nx_ : bp_;                                                            \
+        ++tapB;                                                                                    \
         float* sb_ = smem + B_BASE + (ST) * B_STAGE;                                               \
         _Pragma("unroll") for (int j = 0; j < GB; ++j)                                             \
             NH_GLDS(bp_ + (j * 512 + tid) * 4, sb_ + (j * 512 + wave * 64) * 4)                    \
@@ -214,7 +218,7 @@ __global__ void __launch_bounds__(512) conv_igemm_halo(const ConvArgs a) {
         _Pragma("unroll") for (int t = 0; t < TM; ++t) {                                           \
             const int jr_ = ((SEG_) ? jb1[t] : jb0[t]) + (KW_);                                    \
             const float* ar_ = Sa_ + jr_ * 32;                                                     \
-            const int rs_ = jr_ & 7;                                                               \
+            const int rs_ = (jr_ >> 1) & 7;                                                        \
             _Pragma("unroll") for (int s = (H) * KH_; s < ((H) + 1) * KH_; ++s) {                  \
                 fa_hi[s][t] = *reinterpret_cast<const f32x4*>(ar_ + (((2 * s + g8) ^ rs_) * 4));   \
                 if constexpr (PREC == 1)                                                           \
@@ -231,24 +235,22 @@ __global__ void __launch_bounds__(512) conv_igemm_halo(const ConvArgs a) {
                 }                                                                                  \
             }                                                                                      \
     }
+    // (the three split products -- or the four k-pairs of an f32 quad -- of one accumulator are issued
+    // TM*TN MFMAs apart, so consecutive MFMAs never chain on the same accumulator)
 #define NH_MFMA_HALF(H)                                                                            \
     {                                                                                              \
         _Pragma("unroll") for (int s = (H) * KH_; s < ((H) + 1) * KH_; ++s)                        \
-            _Pragma("unroll") for (int t = 0; t < TM; ++t)                                         \
-                _Pragma("unroll") for (int j = 0; j < TN; ++j) {                                   \
-                    if constexpr (PREC == 1) {                                                     \
-                        const f16x8 ah_ = __builtin_bit_cast(f16x8, fa_hi[s][t]), al_ = __builtin_bit_cast(f16x8, fa_lo[s][t]); \
-                        const f16x8 bh_ = __builtin_bit_cast(f16x8, fb_hi[s][j]), bl_ = __builtin_bit_cast(f16x8, fb_lo[s][j]); \
-                        acc[t][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh_, al_, acc[t][j], 0, 0, 0); \
-                        acc[t][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl_, ah_, acc[t][j], 0, 0, 0); \
-                        acc[t][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh_, ah_, acc[t][j], 0, 0, 0); \
-                    } else {                                                                       \
-                        acc[t][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb_hi[s][j].x, fa_hi[s][t].x, acc[t][j], 0, 0, 0); \
-                        acc[t][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb_hi[s][j].y, fa_hi[s][t].y, acc[t][j], 0, 0, 0); \
-                        acc[t][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb_hi[s][j].z, fa_hi[s][t].z, acc[t][j], 0, 0, 0); \
-                        acc[t][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb_hi[s][j].w, fa_hi[s][t].w, acc[t][j], 0, 0, 0); \
+            _Pragma("unroll") for (int p = 0; p < (PREC == 1 ? 3 : 4); ++p)                        \
+                _Pragma("unroll") for (int t = 0; t < TM; ++t)                                     \
+                    _Pragma("unroll") for (int j = 0; j < TN; ++j) {                               \
+                        if constexpr (PREC == 1) {                                                 \
+                            const f16x8 a_ = __builtin_bit_cast(f16x8, p == 0 ? fa_lo[s][t] : fa_hi[s][t]); \
+                            const f16x8 b_ = __builtin_bit_cast(f16x8, p == 1 ? fb_lo[s][j] : fb_hi[s][j]); \
+                            acc[t][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b_, a_, acc[t][j], 0, 0, 0); \
+                        } else {                                                                   \
+                            acc[t][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb_hi[s][j][p], fa_hi[s][t][p], acc[t][j], 0, 0, 0); \
+                        }                                                                          \
                     }                                                                              \
-                }                                                                                  \
     }
 
     f32x16 acc[TM][TN];
@@ -259,62 +261,157 @@ __global__ void __launch_bounds__(512) conv_igemm_halo(const ConvArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[t][j][r] = 0.f;
 
-    // ---- prologue: halo images 0 and 1 and weight taps 0..2 in flight; wait for image 0 and tap 0
-    // (image 1 precedes tap 0 in the queue) and read half 0 of tap 0.
-    NH_MAP_SEGMENT(0)
-    NH_ISSUE_A(0)
-    NH_ISSUE_A(1)
-    NH_ISSUE_B(0)
-    NH_ISSUE_B(1)
-    NH_ISSUE_B(2)
-    halo_wait_vmcnt<2 * GB>();
-    __builtin_amdgcn_s_barrier();
-
     // Cursor of the tap being multiplied: segment, kw, halo buffer, super-chunk count.
     int segC = 0, kwC = 0, bufC = 0, supC = 0;
-    bool last1 = false, last2 = false;                  // tap it-1 / it-2 closed a super-chunk
-    NH_READ_HALF(0, 0, 0, 0, 0)
+    long long dbg_p1 = 0, dbg_vm = 0, dbg_bar = 0, dbg_t0 = 0;
 
-    // One tap `it`:
-    //   read half 1 of tap it; issue the weights of tap it+3 (their stage was freed by the barrier of
-    //   it-1); MFMAs of half 0;
-    //   counted wait + barrier: the operands of tap it+1 have landed in every wave and every wave
-    //   holds all of tap it in registers -- which frees the weight stage of tap it and, if tap it
-    //   closes a super-chunk, its halo buffer: refill that one with the image after next;
-    //   read half 0 of tap it+1; MFMAs of half 1.
-    // Queue order per iteration j: weights j+3, [halo image if last(j)].  Needed at the barrier of
-    // iteration it: the weights of tap it+1 (issued at it-2) and the image that tap it+1 may open,
-    // issued >= KW >= 3 iterations ago -- except inside the KW = 1 transform segment, where it was
-    // issued at it-1 and only the weights of tap it+3 may still be in flight.
-    for (int it = 0; it < total; ++it) {
-        const int KWc = segC ? 1 : KW0;
-        const bool lastC = kwC + 1 >= KWc;
-        NH_READ_HALF(1, bufC, it & (BST - 1), segC, kwC)
-        NH_ISSUE_B((it + 3) & (BST - 1))
-        __builtin_amdgcn_sched_barrier(0);
-        NH_MFMA_HALF(0)
-        __builtin_amdgcn_sched_barrier(0);
-        if (KWc == 1) halo_wait_vmcnt<GB>();
-        else if (last1 || last2) halo_wait_vmcnt<2 * GB + NA>();
-        else halo_wait_vmcnt<2 * GB>();
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if constexpr (PP) {
+        // ---- Ping-pong K loop.  Waves w and w+4 share a SIMD.  A tap is two phases per wave, each
+        // closed by a workgroup barrier: P1 = memory (issue the DMAs of a later tap, read all MFMA
+        // operands of this tap from LDS, counted wait for the own shares of the next tap); P2 = the
+        // 24 (12) MFMAs from registers at raised priority.  Waves 4-7 run one barrier behind, so on
+        // every SIMD one wave is in P2 while the other is in P1: the older wave of a SIMD otherwise
+        // wins every arbitration, finishes early and idles at the barrier while the younger one does
+        // its memory phase with the matrix pipe empty (measured: 650 vs 80 cycles of barrier wait per
+        // tap).  Slot k = 2*tap (waves 0-3) / 2*tap+1 (waves 4-7):
+        //   tap c is read in slots 2c and 2c+1; its weight stage is refilled with tap c+4 -- issued as
+        //   "tap it+3" in slots 2c+2 / 2c+3 -- and the halo buffer of super-chunk u, last read by its
+        //   last tap L, with image u+2, issued at the first tap of u+1 (slots 2L+2 / 2L+3);
+        //   every wave waits for its own shares of tap it+1 at the end of P1(it), i.e. before the
+        //   barriers that precede slot 2(it+1), and drains its ds_reads before leaving P1.
+        // Queue order per iteration j: [image if first(j)], weights j+3.
+        NH_MAP_SEGMENT(0)
+        NH_ISSUE_A(0)
+        NH_ADVANCE_A()
+        NH_ISSUE_B(0)
+        NH_ISSUE_B(1)
+        NH_ISSUE_B(2)
+        halo_wait_vmcnt<2 * GB>();
         __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_sched_barrier(0);
-        if (lastC) NH_ISSUE_A(bufC)
-        last2 = last1; last1 = lastC;
-        if (lastC) {
-            kwC = 0;
-            bufC ^= 1;
-            if (++supC == nsup0) segC = 1;
-        } else ++kwC;
-        if (it + 1 < total) NH_READ_HALF(0, bufC, (it + 1) & (BST - 1), segC, kwC)
-        __builtin_amdgcn_sched_barrier(0);
-        NH_MFMA_HALF(1)
-        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (DBG) dbg_t0 = (long long)__builtin_amdgcn_s_memtime();
+        const bool grp_y = wave >= 4;
+        if (grp_y) __builtin_amdgcn_s_barrier();
+        bool prev_first = false;
+        for (int it = 0; it < total; ++it) {
+            const int KWc = segC ? 1 : KW0;
+            const bool first = kwC == 0;
+            long long tq0 = 0, tq1 = 0, tq2 = 0;
+            if constexpr (DBG) tq0 = (long long)__builtin_amdgcn_s_memtime();
+            if (first) {
+                NH_ISSUE_A(bufC ^ 1)
+                NH_ADVANCE_A()
+            }
+            NH_ISSUE_B((it + 3) & (BST - 1))
+            NH_READ_HALF(0, bufC, it & (BST - 1), segC, kwC)
+            NH_READ_HALF(1, bufC, it & (BST - 1), segC, kwC)
+            if constexpr (DBG) tq1 = (long long)__builtin_amdgcn_s_memtime();
+            if (KWc == 1) halo_wait_vmcnt<GB>();
+            else if (first || prev_first) halo_wait_vmcnt<2 * GB + NA>();
+            else halo_wait_vmcnt<2 * GB>();
+            if constexpr (DBG) tq2 = (long long)__builtin_amdgcn_s_memtime();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            if constexpr (DBG) {
+                const long long tq3 = (long long)__builtin_amdgcn_s_memtime();
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                dbg_p1 += tq1 - tq0; dbg_vm += tq2 - tq1; dbg_bar += tq3 - tq2;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_setprio(1);
+            NH_MFMA_HALF(0)
+            NH_MFMA_HALF(1)
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            prev_first = first;
+            if (++kwC >= KWc) {
+                kwC = 0;
+                bufC ^= 1;
+                if (++supC == nsup0) segC = 1;
+            }
+        }
+        if (!grp_y) __builtin_amdgcn_s_barrier();
+    } else {
+        // ---- Lockstep K loop with half-tap register pipelining.
+        // prologue: halo images 0 and 1 and weight taps 0..2 in flight; wait for image 0 and tap 0
+        // (image 1 precedes tap 0 in the queue) and read half 0 of tap 0.
+        NH_MAP_SEGMENT(0)
+        NH_ISSUE_A(0)
+        NH_ADVANCE_A()
+        NH_ISSUE_A(1)
+        NH_ADVANCE_A()
+        NH_ISSUE_B(0)
+        NH_ISSUE_B(1)
+        NH_ISSUE_B(2)
+        halo_wait_vmcnt<2 * GB>();
+        __builtin_amdgcn_s_barrier();
+        bool last1 = false, last2 = false;              // tap it-1 / it-2 closed a super-chunk
+        NH_READ_HALF(0, 0, 0, 0, 0)
+
+        // One tap `it`:
+        //   issue the weights of tap it+3 (their stage was freed by the barrier of it-1); read half 1
+        //   of tap it; MFMAs of half 0;
+        //   counted wait + barrier: the operands of tap it+1 have landed in every wave and every wave
+        //   holds all of tap it in registers -- which frees the weight stage of tap it and, if tap it
+        //   closes a super-chunk, its halo buffer: refill that one with the image after next;
+        //   read half 0 of tap it+1; MFMAs of half 1.
+        // Queue order per iteration j: weights j+3, [halo image if last(j)].  Needed at the barrier of
+        // iteration it: the weights of tap it+1 (issued at it-2) and the image that tap it+1 may open,
+        // issued >= KW >= 3 iterations ago -- except inside the KW = 1 transform segment, where it was
+        // issued at it-1 and only the weights of tap it+3 may still be in flight.
+        // (Interleaving the reads and DMAs 1:1 between the MFMAs with sched_group_barrier measured 4 %
+        // slower than issuing them ahead of the burst.)
+        if constexpr (DBG) dbg_t0 = (long long)__builtin_amdgcn_s_memtime();
+        for (int it = 0; it < total; ++it) {
+            const int KWc = segC ? 1 : KW0;
+            const bool lastC = kwC + 1 >= KWc;
+            NH_ISSUE_B((it + 3) & (BST - 1))
+            NH_READ_HALF(1, bufC, it & (BST - 1), segC, kwC)
+            __builtin_amdgcn_sched_barrier(0);
+            NH_MFMA_HALF(0)
+            __builtin_amdgcn_sched_barrier(0);
+            long long tq0 = 0, tq1 = 0;
+            if constexpr (DBG) tq0 = (long long)__builtin_amdgcn_s_memtime();
+            if (KWc == 1) halo_wait_vmcnt<GB>();
+            else if (last1 || last2) halo_wait_vmcnt<2 * GB + NA>();
+            else halo_wait_vmcnt<2 * GB>();
+            if constexpr (DBG) tq1 = (long long)__builtin_amdgcn_s_memtime();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if constexpr (DBG) {
+                const long long tq2 = (long long)__builtin_amdgcn_s_memtime();
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                dbg_vm += tq1 - tq0; dbg_bar += tq2 - tq1;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (lastC) {
+                NH_ISSUE_A(bufC)
+                NH_ADVANCE_A()
+            }
+            last2 = last1; last1 = lastC;
+            if (lastC) {
+                kwC = 0;
+                bufC ^= 1;
+                if (++supC == nsup0) segC = 1;
+            } else ++kwC;
+            NH_READ_HALF(0, bufC, (it + 1) & (BST - 1), segC, kwC)       // (past the last tap: a harmless read)
+            __builtin_amdgcn_sched_barrier(0);
+            NH_MFMA_HALF(1)
+            __builtin_amdgcn_sched_barrier(0);
+        }
     }
     halo_wait_vmcnt<0>();                               // dummy DMAs past the end still target LDS
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+    if constexpr (DBG) {        // per wave 0 / wave 7: [loop cycles, P1 issue+reads, vmcnt wait, lgkm+barrier wait]
+        if (a.dbg && (tid == 0 || tid == 448)) {
+            long long* d = a.dbg + ((size_t)blockIdx.x * 2 + (tid ? 1 : 0)) * 4;
+            d[0] = (long long)__builtin_amdgcn_s_memtime() - dbg_t0; d[1] = dbg_p1; d[2] = dbg_vm; d[3] = dbg_bar;
+        }
+    }
+
 
 #undef NH_MAP_ROW
 #undef NH_MAP_SEGMENT
@@ -329,17 +426,17 @@ __global__ void __launch_bounds__(512) conv_igemm_halo(const ConvArgs a) {
     conv_epilogue<TM, TN, PREC, 512, HBM, BN>(a, acc, smem, m0, wm * 64, wn * TN * 32, nt * BN, tid, lane);
 }
 
-template <int BN, int PREC> static void launch_halo_t(const ConvArgs& a, hipStream_t s) {
+template <int BN, int PREC, int PP = 1, int DBG = 0> static void launch_halo_t(const ConvArgs& a, hipStream_t s) {
     constexpr size_t lds = (size_t)(2 * HR * 32 + BST * 32 * BN) * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_halo<BN, PREC>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_halo<BN, PREC, PP, DBG>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
     const int mtiles = (a.M + HBM - 1) / HBM;
     const int grid = mtiles * (a.N / BN);
-    hipLaunchKernelGGL((conv_igemm_halo<BN, PREC>), dim3(grid), dim3(512), lds, s, a);
+    hipLaunchKernelGGL((conv_igemm_halo<BN, PREC, PP, DBG>), dim3(grid), dim3(512), lds, s, a);
 }
 
 bool conv_igemm_halo_eligible(const ConvArgs& a) {
@@ -362,10 +459,18 @@ bool conv_igemm_halo_eligible(const ConvArgs& a) {
 void launch_conv_igemm_halo(const ConvArgs& a0, hipStream_t s) {
     ConvArgs a = a0;
     a.fdWP = make_fastdiv((uint32_t)(a.Wo + a.seg[0].KW - 1));
-    if (a.prec == 1) {
-        if (a.N % 128 == 0) launch_halo_t<128, 1>(a, s); else launch_halo_t<64, 1>(a, s);
+    // NHANS_HALO_LOCKSTEP=1 selects the lockstep K loop (A/B experiments)
+    static const bool pp = [] { const char* e = getenv("NHANS_HALO_LOCKSTEP"); return !(e && atoi(e)); }();
+    const bool wide = a.N % 128 == 0;
+    if (a.prec == 1 && a.dbg) {
+        if (pp) { if (wide) launch_halo_t<128, 1, 1, 1>(a, s); else launch_halo_t<64, 1, 1, 1>(a, s); }
+        else { if (wide) launch_halo_t<128, 1, 0, 1>(a, s); else launch_halo_t<64, 1, 0, 1>(a, s); }
+    } else if (a.prec == 1) {
+        if (pp) { if (wide) launch_halo_t<128, 1, 1>(a, s); else launch_halo_t<64, 1, 1>(a, s); }
+        else { if (wide) launch_halo_t<128, 1, 0>(a, s); else launch_halo_t<64, 1, 0>(a, s); }
     } else {
-        if (a.N % 128 == 0) launch_halo_t<128, 0>(a, s); else launch_halo_t<64, 0>(a, s);
+        if (pp) { if (wide) launch_halo_t<128, 0, 1>(a, s); else launch_halo_t<64, 0, 1>(a, s); }
+        else { if (wide) launch_halo_t<128, 0, 0>(a, s); else launch_halo_t<64, 0, 0>(a, s); }
     }
 }
 

@@ -40,8 +40,19 @@ def _cont_embed(W, n, scope):
     return z @ W[scope + "_dense3/w"].astype(F64)
 
 
+def kmat(w4):
+    """HWIO conv weight [KH, KW, C, N] -> [K, N] in the K order the conv kernels walk: filter row,
+    32-channel chunk, filter column, channel within the chunk.  The KW taps of one (row, chunk) are
+    adjacent so that the halo kernel (conv_igemm_halo.hip) streams its weights strictly sequentially
+    while one staged activation image serves all KW of them.  (C = 1 convs are not GEMMs: plain order.)"""
+    kh, kw, c, n = w4.shape
+    if c % 32:
+        return w4.reshape(-1, n)
+    return w4.reshape(kh, kw, c // 32, 32, n).transpose(0, 2, 1, 3, 4).reshape(-1, n)
+
+
 def pack_igemm(wkn, npad=None):
-    """[K, N] (K = kh*kw*cin in HWIO order, multiple of 32) -> float32 [K/32][Npad/32][4][64][4]
+    """[K, N] (K in kmat() order, multiple of 32) -> float32 [K/32][Npad/32][4][64][4]
     so that lane l of MFMA (q, e) of chunk c, n-tile t reads W[32c + 8q + 4(l>>5) + e][32t + (l&31)]
     as element e of one 16-byte vector (conv_igemm.hip)."""
     k, n = wkn.shape
@@ -125,14 +136,14 @@ def fold_arrays(W, kind, split_f16=True):
     for i, g in enumerate(spec.tower_geometry()):
         p, s = "t%d" % i, "embedding/" + g["name"]
         s1, h1 = _bn(W, s + "_conv1")
-        w1 = w64(s + "_conv1/w").reshape(-1, g["cout"]) * s1
+        w1 = kmat(w64(s + "_conv1/w")) * s1
         if g["cin"] == 1:
             out[p + ".c1.w"] = w1.reshape(-1)
         else:
             emit(p + ".c1", [(p + ".c1.wpk", w1)])
         out[p + ".c1.cb"] = h1
         sa, ha = _bn(W, s + "_addition")
-        w2 = w64(s + "_conv2/w").reshape(-1, g["cout"]) * sa
+        w2 = kmat(w64(s + "_conv2/w")) * sa
         wt = w64(s + "_transform/w").reshape(g["cin"], g["cout"]) * sa
         if g["cin"] == 1:
             out[p + ".c2.idw"] = wt.reshape(-1)
@@ -148,12 +159,12 @@ def fold_arrays(W, kind, split_f16=True):
         p, s, c = "m%d" % i, g["name"], g["cout"]
         s1, h1 = _bn(W, s + "_conv1")
         sa, ha = _bn(W, s + "_addition")
-        w1 = w64(s + "_conv1/w").reshape(-1, c) * s1
+        w1 = kmat(w64(s + "_conv1/w")) * s1
         if g["cin"] == 1:
             out[p + ".c1.w"] = w1.reshape(-1)
         else:
             emit(p + ".c1", [(p + ".c1.wpk", w1)])
-        w2 = w64(s + "_conv2/w").reshape(-1, c) * sa
+        w2 = kmat(w64(s + "_conv2/w")) * sa
         extra_bias = w64(s + "_conv2/b").reshape(-1)
         if g["cin"] == 1:
             out[p + ".c2.idw"] = w64(s + "_transform/w").reshape(-1) * sa
@@ -180,7 +191,7 @@ def fold_arrays(W, kind, split_f16=True):
 
     # --- head (SN/main.py:232-242)
     s, h = _bn(W, "last_conv")
-    emit("head.conv", [("head.conv.wpk", w64("last_conv/w").reshape(-1, 512) * s)])
+    emit("head.conv", [("head.conv.wpk", kmat(w64("last_conv/w")) * s)])
     out["head.conv.cb"] = h
     emit("head.dense", [("head.dense.wpk", w64("last_dense/w"))], 256)
     cb = np.zeros(256)

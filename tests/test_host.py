@@ -91,7 +91,10 @@ def test_fold_blob_structure(weights_denoiser):
     W = weights_denoiser
     sc = (W["resblock1_2_conv1/gamma"].astype(np.float64) /
           np.sqrt(W["resblock1_2_conv1/pop_variance"].astype(np.float64) + 1e-3)).reshape(-1)
-    w = W["resblock1_2_conv1/w"].astype(np.float64).reshape(-1, 64) * sc
+    w4 = W["resblock1_2_conv1/w"].astype(np.float64)
+    w = fold.kmat(w4) * sc
+    # K order: filter row, 32-channel chunk, filter column, channel
+    assert w.shape == (4 * 4 * 64, 64) and w[(1 * 2 + 1) * 4 * 32 + 2 * 32 + 5, 7] == w4[1, 2, 32 + 5, 7] * sc[7]
     np.testing.assert_array_equal(arrs["m1.c1.wpk"], fold.pack_igemm(w))
     blob = fold.write_blob({"b": np.arange(5, dtype=np.float32), "a": np.ones(3, dtype=np.float32)})
     magic, ver, n, total = struct.unpack_from("<8sIIQ", blob, 0)

@@ -1,0 +1,44 @@
+"""Dev tool: where the K loop of the halo conv kernel (conv_igemm_halo.hip) spends its cycles, from
+s_memtime stamps of waves 0 and 7 of every workgroup (option debug_cycles_ptr):
+    python tools/halo_phase_cycles.py [block 0..7] [frames]"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import nhans_amd  # noqa: E402,F401
+from nhans_amd import engine, spec, synth  # noqa: E402
+from nhans_amd.apply import normalise, trim_to_frames  # noqa: E402
+
+
+def main():
+    block = int(sys.argv[1]) if len(sys.argv) > 1 else 3
+    frames = int(sys.argv[2]) if len(sys.argv) > 2 else 998
+    os.environ.setdefault("NHANS_CONV_VARIANT", "2")
+    eng = engine.Engine("denoiser", precision="f16x3")
+    mix = trim_to_frames(normalise(synth.mixture(0, 10.0)))
+    lm, _ = eng.stft_features(torch.from_numpy(mix).cuda(), [0, len(mix)])
+    ea = torch.zeros(1, 512, device="cuda")
+    dbg = torch.zeros(8 * (1 << 20), dtype=torch.int64, device="cuda")
+    eng.set_option("debug_cycles_ptr", dbg.data_ptr())
+    eng.set_option("frames_per_chunk", frames)
+    for _ in range(2):
+        dbg.zero_()
+        eng.block_output(lm, [0, lm.shape[0]], ea, ea, 0, frames, block)
+        torch.cuda.synchronize()
+    g = spec.main_geometry()[block]
+    bn = 128 if g["cout"] >= 128 else 64
+    nblk = -(-(frames * g["hout"] * g["wout"]) // 256) * (g["cout"] // bn)
+    d = dbg.cpu().numpy()[:nblk * 8].reshape(nblk, 2, 4).astype(np.float64)   # the last launch = this block's conv2
+    taps = g["kh"] * g["kw"] * g["cout"] // 32 + (g["cin"] // 32 if g["cin"] not in (1, g["cout"]) else 0)
+    for w, name in ((0, "wave 0"), (1, "wave 7")):
+        loop, p1, vm, bar = (d[:, w, i].mean() / taps for i in range(4))
+        print("block %d conv2 %s: %d taps; cycles per tap: loop %.0f | P1 issue+reads %.0f | vmcnt wait %.0f | lgkm+barrier %.0f | rest %.0f"
+              % (block, name, taps, loop, p1, vm, bar, loop - p1 - vm - bar))
+
+
+if __name__ == "__main__":
+    main()
