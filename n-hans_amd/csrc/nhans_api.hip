@@ -110,7 +110,8 @@ struct nhans_ctx {
 
     int prec = 0;           // 0: f32 MFMA, 1: split-f16 x3 MFMA (activations in split NHWC)
     int conv_variant = -1;  // 0: 128-pixel register-staged conv kernel, 1: 256-pixel LDS-DMA kernel,
-                            // -1: automatic (measured best: LDS-DMA for split-f16, register-staged for f32)
+                            // 2: halo-reuse / wave-specialised LDS-DMA kernel where the conv allows it, else 1;
+                            // -1: automatic (measured best: 2 for split-f16, register-staged for f32)
     long long* dbg = nullptr;   // dev tool: per-workgroup cycle stamps of the last conv launch
 
     const float* A(const std::string& n) const {
@@ -196,7 +197,7 @@ void fill_epilogue_defaults(nhans_ctx* c, ConvArgs& a) {
     a.idw = nullptr; a.idH = a.idW = 0; a.idsh = a.idsw = 1; a.relu = 1; a.aux = nullptr; a.aux_ld = 0;
     a.cb_stride = 0;
     a.prec = c->prec; a.out_split = c->prec; a.id_split = 0; a.ws = nullptr;
-    a.variant = c->conv_variant >= 0 ? c->conv_variant : (c->prec == 1 ? 1 : 0);
+    a.variant = c->conv_variant >= 0 ? c->conv_variant : (c->prec == 1 ? 2 : 0);
     a.dbg = c->dbg;
 }
 

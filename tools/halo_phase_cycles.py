@@ -32,12 +32,15 @@ def main():
     g = spec.main_geometry()[block]
     bn = 128 if g["cout"] >= 128 else 64
     nblk = -(-(frames * g["hout"] * g["wout"]) // 256) * (g["cout"] // bn)
-    d = dbg.cpu().numpy()[:nblk * 8].reshape(nblk, 2, 4).astype(np.float64)   # the last launch = this block's conv2
+    d = dbg.cpu().numpy()[:nblk * 12].reshape(nblk, 3, 4).astype(np.float64)   # the last launch = this block's conv2
     taps = g["kh"] * g["kw"] * g["cout"] // 32 + (g["cin"] // 32 if g["cin"] not in (1, g["cout"]) else 0)
-    for w, name in ((0, "wave 0"), (1, "wave 7")):
-        loop, p1, vm, bar = (d[:, w, i].mean() / taps for i in range(4))
-        print("block %d conv2 %s: %d taps; cycles per tap: loop %.0f | P1 issue+reads %.0f | vmcnt wait %.0f | lgkm+barrier %.0f | rest %.0f"
-              % (block, name, taps, loop, p1, vm, bar, loop - p1 - vm - bar))
+    for w, name in ((0, "consumer wave 0"), (1, "consumer wave 7")):
+        loop, bar = d[:, w, 0].mean() / taps, d[:, w, 3].mean() / taps
+        print("block %d conv2 %s: %d taps; cycles per tap: loop %.0f | lgkm+barrier %.0f | reads+MFMA %.0f"
+              % (block, name, taps, loop, bar, loop - bar))
+    loop, iss, vm, bar = (d[:, 2, i].mean() / taps for i in range(4))
+    print("block %d conv2 producer wave 8: cycles per tap: loop %.0f | DMA issue %.0f | vmcnt wait %.0f | barrier %.0f"
+          % (block, loop, iss, vm, bar))
 
 
 if __name__ == "__main__":
