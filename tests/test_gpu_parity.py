@@ -141,6 +141,28 @@ def test_ten_second_clip_selected_frames(eng_d):
     assert np.abs(lg.cpu().numpy()[fr] - g["logits"]).max() < LOGIT_TOL
 
 
+@pytest.mark.parametrize("variant", [0, 1, 2])
+@pytest.mark.parametrize("prec", ["f32", "f16x3"])
+def test_every_conv_kernel_variant(_eng_d, prec, variant):
+    """The three conv kernels (register-staged, LDS-DMA, halo + producer/consumer waves) in both
+    arithmetic modes against the same golden logits: 308-frame clip, and 998 frames so that tiles
+    span many frame-windows and the ragged last tile of every layer is exercised."""
+    _eng_d.set_precision(prec)
+    _eng_d.set_option("conv_variant", variant)
+    try:
+        for case, n in (("case_exp2", 308), ("case_synth10s", 998)):
+            g = load_case(case)
+            lm = torch.from_numpy(g["logmag"]).cuda()
+            ea = torch.from_numpy(g["emb_a"][None]).cuda()
+            eb = torch.from_numpy(g["emb_b"][None]).cuda()
+            lg = _eng_d.mask_net(lm, [0, n], ea, eb)[0].cpu().numpy()
+            ref = g["logits"]
+            got = lg[g["frames"]] if "frames" in g else lg
+            assert np.abs(got - ref).max() < LOGIT_TOL, (case, prec, variant)
+    finally:
+        _eng_d.set_option("conv_variant", -1)
+
+
 def test_separator_model(eng_s):
     g = load_case("case_separator")
     mix = apply.trim_to_frames(apply.normalise(synth.mixture(3, 2.0)))
