@@ -235,9 +235,9 @@ __global__ void __launch_bounds__((NCW + NPW) * 64) conv_igemm_halo(const ConvAr
         }
         halo_wait_vmcnt<0>();                           // dummy DMAs past the end still target LDS
         __builtin_amdgcn_s_barrier();
-        if constexpr (DBG) {                            // record 2: producer wave 8
-            if (a.dbg && tid == NCW * 64) {
-                long long* d = a.dbg + ((size_t)blockIdx.x * 3 + 2) * 4;
+        if constexpr (DBG) {                            // one record per wave
+            if (a.dbg && lane == 0) {
+                long long* d = a.dbg + ((size_t)blockIdx.x * (NCW + NPW) + wave) * 4;
                 d[0] = (long long)__builtin_amdgcn_s_memtime() - dbg_t0; d[1] = dbg_is; d[2] = dbg_vm; d[3] = dbg_bar;
             }
         }
@@ -358,9 +358,9 @@ __global__ void __launch_bounds__((NCW + NPW) * 64) conv_igemm_halo(const ConvAr
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();                       // the producers have drained every DMA
-    if constexpr (DBG) {                                // records 0 / 1: consumer waves 0 / 7
-        if (a.dbg && (tid == 0 || tid == 448)) {
-            long long* d = a.dbg + ((size_t)blockIdx.x * 3 + (tid ? 1 : 0)) * 4;
+    if constexpr (DBG) {                                // one record per wave
+        if (a.dbg && lane == 0) {
+            long long* d = a.dbg + ((size_t)blockIdx.x * (NCW + NPW) + wave) * 4;
             d[0] = (long long)__builtin_amdgcn_s_memtime() - dbg_t0; d[1] = 0; d[2] = 0; d[3] = dbg_bar;
         }
     }

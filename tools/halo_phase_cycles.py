@@ -32,15 +32,14 @@ def main():
     g = spec.main_geometry()[block]
     bn = 128 if g["cout"] >= 128 else 64
     nblk = -(-(frames * g["hout"] * g["wout"]) // 256) * (g["cout"] // bn)
-    d = dbg.cpu().numpy()[:nblk * 12].reshape(nblk, 3, 4).astype(np.float64)   # the last launch = this block's conv2
+    d = dbg.cpu().numpy()[:nblk * 48].reshape(nblk, 12, 4).astype(np.float64)   # the last launch = this block's conv2
     taps = g["kh"] * g["kw"] * g["cout"] // 32 + (g["cin"] // 32 if g["cin"] not in (1, g["cout"]) else 0)
-    for w, name in ((0, "consumer wave 0"), (1, "consumer wave 7")):
-        loop, bar = d[:, w, 0].mean() / taps, d[:, w, 3].mean() / taps
-        print("block %d conv2 %s: %d taps; cycles per tap: loop %.0f | lgkm+barrier %.0f | reads+MFMA %.0f"
-              % (block, name, taps, loop, bar, loop - bar))
-    loop, iss, vm, bar = (d[:, 2, i].mean() / taps for i in range(4))
-    print("block %d conv2 producer wave 8: cycles per tap: loop %.0f | DMA issue %.0f | vmcnt wait %.0f | barrier %.0f"
-          % (block, loop, iss, vm, bar))
+    m = d.mean(0) / taps
+    print("block %d conv2, %d taps, %d workgroups; cycles per tap" % (block, taps, nblk))
+    for w in range(8):
+        print("  consumer wave %d: loop %.0f | lgkm+barrier %.0f | reads+MFMA %.0f" % (w, m[w, 0], m[w, 3], m[w, 0] - m[w, 3]))
+    for w in range(8, 12):
+        print("  producer wave %d: loop %.0f | DMA issue %.0f | vmcnt wait %.0f | barrier %.0f" % (w, m[w, 0], m[w, 1], m[w, 2], m[w, 3]))
 
 
 if __name__ == "__main__":
