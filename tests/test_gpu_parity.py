@@ -163,6 +163,20 @@ def test_every_conv_kernel_variant(_eng_d, prec, variant):
         _eng_d.set_option("conv_variant", -1)
 
 
+def test_mask_net_is_bitwise_reproducible(eng_d):
+    """Race screen for the LDS-DMA pipelines (counted vmcnt + raw barriers): a stage read before its
+    DMA landed, or overwritten while still being read, shows up as run-to-run differences long before
+    it breaks a tolerance.  998 frames = thousands of workgroups per layer, 4 runs, all bits equal."""
+    g = load_case("case_synth10s")
+    lm = torch.from_numpy(g["logmag"]).cuda()
+    ea = torch.from_numpy(g["emb_a"][None]).cuda()
+    eb = torch.from_numpy(g["emb_b"][None]).cuda()
+    first = eng_d.mask_net(lm, [0, 998], ea, eb)[0].clone()
+    for _ in range(3):
+        again = eng_d.mask_net(lm, [0, 998], ea, eb)[0]
+        assert torch.equal(first, again)
+
+
 def test_separator_model(eng_s):
     g = load_case("case_separator")
     mix = apply.trim_to_frames(apply.normalise(synth.mixture(3, 2.0)))
