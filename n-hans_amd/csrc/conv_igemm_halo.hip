@@ -406,10 +406,15 @@ void launch_conv_igemm_halo(const ConvArgs& a0, hipStream_t s) {
     ConvArgs a = a0;
     a.fdWP = make_fastdiv((uint32_t)(a.Wo + a.seg[0].KW - 1));
     const bool wide = a.N % 128 == 0;
-    if (a.prec == 1 && a.dbg) {
-        if (wide) launch_halo_t<128, 1, 1>(a, s); else launch_halo_t<64, 1, 1>(a, s);
+    static const int abl = [] { const char* e = getenv("NHANS_ABLATE"); return e ? atoi(e) : 0; }();
+    if (a.prec == 1 && a.dbg) {     // cycle stamps, optionally of an ablated loop
+#define NH_DBG_CASE(V) case V: if (wide) launch_halo_t<128, 1, 1, V>(a, s); else launch_halo_t<64, 1, 1, V>(a, s); break;
+        switch (abl) {
+            NH_DBG_CASE(10) NH_DBG_CASE(16) NH_DBG_CASE(32) NH_DBG_CASE(48)
+            default: if (wide) launch_halo_t<128, 1, 1>(a, s); else launch_halo_t<64, 1, 1>(a, s);
+        }
+#undef NH_DBG_CASE
     } else if (a.prec == 1) {
-        static const int abl = [] { const char* e = getenv("NHANS_ABLATE"); return e ? atoi(e) : 0; }();
 #define NH_ABL_CASE(V) case V: if (wide) launch_halo_t<128, 1, 0, V>(a, s); else launch_halo_t<64, 1, 0, V>(a, s); break;
         switch (abl) {              // timing experiments only: results are wrong for abl != 0
             NH_ABL_CASE(1) NH_ABL_CASE(2) NH_ABL_CASE(4) NH_ABL_CASE(5) NH_ABL_CASE(8) NH_ABL_CASE(10)
