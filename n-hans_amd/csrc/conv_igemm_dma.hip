@@ -18,6 +18,7 @@
 //     that chunk it+1 has landed while chunk it+2 stays in flight across the raw `s_barrier`.
 //     (`__syncthreads()` would drain the queue: hipcc fences LDS-DMA with vmcnt(0).)
 #include "conv_epilogue.h"
+#include <algorithm>
 #include <cstdlib>
 
 namespace nhans {
@@ -30,7 +31,10 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
 }
 }  // namespace
 
-template <int BN, int PREC, int ABL = 0, int PINGPONG = 0>   // ABL: timing ablations (1: A from the zero page, 2: B always chunk 0, 4: no epilogue)
+// GRP: the K loop sums in groups of a.kgroup chunks (each group from a zeroed accumulator, groups
+// added in order) -- the arithmetic of a split-K launch, so that a layer's results do not depend on
+// whether its launch was small enough to be split (batch- and shard-invariance stay bitwise).
+template <int BN, int PREC, int ABL = 0, int PINGPONG = 0, int GRP = 0>   // ABL: timing ablations (1: A from the zero page, 2: B always chunk 0, 4: no epilogue)
 __global__ void __launch_bounds__(512) conv_igemm_dma(const ConvArgs a) {
     constexpr int WN = 2, WM = 4;                     // wave grid: 4 (pixels) x 2 (channels)
     constexpr int TM = DBM / WM / 32;                  // 2
@@ -214,9 +218,39 @@ __global__ void __launch_bounds__(512) conv_igemm_dma(const ConvArgs a) {
     int total = 0;
     for (int s = 0; s < a.nseg; ++s) total += a.seg[s].nchunks;
 
+    // Split-K (launches too small to fill the chip: the head's dense layer and the embedding tower at
+    // one or two clips): blockIdx.y owns a contiguous range of the chunks of the (single) segment.
+    const int ksplit = gridDim.y, kz = blockIdx.y;
+    f32x16 tot[GRP ? TM : 1][GRP ? TN : 1];
+    int gleft = GRP ? a.kgroup : 0;
+    if constexpr (GRP) {
+#pragma unroll
+        for (int t = 0; t < TM; ++t)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) tot[t][j][r] = 0.f;
+    }
+    int cbeg = 0;
+    if (ksplit > 1) {
+        const int cps = a.kgroup;                      // one group per split
+        cbeg = kz * cps;
+        total = total - cbeg < cps ? total - cbeg : cps;
+    }
+
     // prologue: chunks 0 and 1 in flight, wait for chunk 0 only
     long long t_loop = 0, t_epi = 0;
     NH_ENTER_SEGMENT(0)
+    if (cbeg) {                                        // cursor to chunk cbeg: K order (row, chunk, column)
+        const int per_kh = (sC >> 5) * sKW;
+        kh = cbeg / per_kh;
+        const int r_ = cbeg - kh * per_kh;
+        const int cc_ = r_ / sKW;
+        kw = r_ - cc_ * sKW;
+        c0 = cc_ * DBK;
+        lchunk = cbeg;
+        NH_TAP()
+    }
     NH_ISSUE(0)
     if (total > 1) {
         NH_ISSUE(1)
@@ -275,6 +309,19 @@ __global__ void __launch_bounds__(512) conv_igemm_dma(const ConvArgs a) {
             NH_READ_FRAGS(st)
             if (a.dbg) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_sched_barrier(0); const long long t = (long long)__builtin_amdgcn_s_memtime(); ph1 += t - tq; tq = t; }
             NH_MFMA_FRAGS()
+            if constexpr (GRP) {
+                if (ksplit == 1 && --gleft == 0) {      // close the group: tot += acc, acc = 0
+                    gleft = a.kgroup;
+#pragma unroll
+                    for (int t = 0; t < TM; ++t)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j) {
+                            tot[t][j] += acc[t][j];
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) acc[t][j][r] = 0.f;
+                        }
+                }
+            }
             __builtin_amdgcn_sched_barrier(0);
             if (a.dbg) { const long long t = (long long)__builtin_amdgcn_s_memtime(); ph2 += t - tq; tq = t; }
             // chunk it+1 must have landed (in every wave) before anyone reads it; chunk it+2 stays in flight
@@ -300,6 +347,67 @@ __global__ void __launch_bounds__(512) conv_igemm_dma(const ConvArgs a) {
 #undef NH_MFMA_FRAGS
 
     if (a.dbg) t_epi = (long long)__builtin_amdgcn_s_memtime();
+    if constexpr (GRP) {
+        if (ksplit == 1) {                              // last (partial) group, then the sum is the result
+#pragma unroll
+            for (int t = 0; t < TM; ++t)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    if (gleft != a.kgroup) tot[t][j] += acc[t][j];
+                    acc[t][j] = tot[t][j];
+                }
+        }
+    }
+    if (ksplit > 1) {
+        // Every workgroup parks its partial accumulator tile in scratch (thread-private slots, so no
+        // transposition: piece q of thread t of split z), then takes a ticket; the last one to arrive
+        // sums the partials in the fixed order z = 0..ksplit-1 -- bitwise reproducible whoever is last
+        // -- and runs the epilogue.  Fences are agent scope: the splits of a tile may sit on different
+        // XCDs, whose L2s are not coherent with each other inside a kernel.
+        constexpr int NQ = TM * TN * 4;
+        const size_t slot = (size_t)512 * NQ * 4;      // floats per (tile, split)
+        float* part = a.kscratch + ((size_t)L * ksplit + kz) * slot + tid * 4;
+#pragma unroll
+        for (int t = 0; t < TM; ++t)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4 v = {acc[t][j][4 * q], acc[t][j][4 * q + 1], acc[t][j][4 * q + 2], acc[t][j][4 * q + 3]};
+                    *reinterpret_cast<f32x4*>(part + ((t * TN + j) * 4 + q) * 2048) = v;
+                }
+        __threadfence();
+        __syncthreads();
+        int* ticket = reinterpret_cast<int*>(smem);
+        if (tid == 0)
+            ticket[0] = __hip_atomic_fetch_add(a.kcounter + L, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        const int old = ticket[0];
+        __syncthreads();
+        if (old != ksplit - 1) return;
+        __threadfence();
+        if (tid == 0) a.kcounter[L] = 0;               // ready for the next launch on this stream
+#pragma unroll
+        for (int t = 0; t < TM; ++t)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[t][j][r] = 0.f;
+        const float* all = a.kscratch + (size_t)L * ksplit * slot + tid * 4;
+#pragma unroll 1
+        for (int z = 0; z < ksplit; ++z) {
+#pragma unroll
+            for (int t = 0; t < TM; ++t)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(all + z * slot + ((t * TN + j) * 4 + q) * 2048));
+                        acc[t][j][4 * q] += v.x; acc[t][j][4 * q + 1] += v.y;
+                        acc[t][j][4 * q + 2] += v.z; acc[t][j][4 * q + 3] += v.w;
+                    }
+        }
+    }
     if constexpr (ABL & 4) {
         float chk = 0.f;                                 // keep every MFMA alive
 #pragma unroll
@@ -322,18 +430,41 @@ __global__ void __launch_bounds__(512) conv_igemm_dma(const ConvArgs a) {
     }
 }
 
-template <int BN, int PREC, int ABL = 0, int PINGPONG = 0>
-static void launch_dma_t(const ConvArgs& a, hipStream_t s) {
+template <int BN, int PREC, int ABL = 0, int PINGPONG = 0, int GRP = 0>
+static void launch_dma_g(const ConvArgs& a, int grid, int ks, hipStream_t s) {
     constexpr size_t lds = (size_t)DSTAGES * (DBM * 32 + DBK * BN) * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_dma<BN, PREC, ABL, PINGPONG>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_dma<BN, PREC, ABL, PINGPONG, GRP>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
-    const int mtiles = (a.M + DBM - 1) / DBM;
-    const int grid = mtiles * (a.N / BN);
-    hipLaunchKernelGGL((conv_igemm_dma<BN, PREC, ABL, PINGPONG>), dim3(grid), dim3(512), lds, s, a);
+    hipLaunchKernelGGL((conv_igemm_dma<BN, PREC, ABL, PINGPONG, GRP>), dim3(grid, ks), dim3(512), lds, s, a);
+}
+
+template <int BN, int PREC, int ABL = 0, int PINGPONG = 0>
+static void launch_dma_t(const ConvArgs& a0, hipStream_t s) {
+    const int mtiles = (a0.M + DBM - 1) / DBM;
+    const int grid = mtiles * (a0.N / BN);
+    if constexpr (ABL || PINGPONG) {
+        launch_dma_g<BN, PREC, ABL, PINGPONG, 0>(a0, grid, 1, s);
+    } else {
+        // Grouped summation / split-K plan.  The group size depends on the layer only (K), never on
+        // the launch: single-segment convs with >= 32 chunks sum in <= 32 groups of >= 8 chunks.  A
+        // launch that would leave most CUs idle (the head's dense layer, the embedding tower at a
+        // few clips) runs one workgroup per (tile, group) -- split-K -- when the scratch holds
+        // grid x groups accumulator tiles (512 threads x TM*TN*16 floats); any other launch walks the
+        // groups in order inside the K loop.  Same additions in the same order either way.
+        ConvArgs a = a0;
+        const int total = a.seg[0].nchunks;
+        // (a.kgroup < 0 on entry = the caller marks the layers whose launches can be that small)
+        a.kgroup = (a0.kgroup < 0 && a.nseg == 1 && total >= 32 && a.kscratch && a.kcounter) ? std::max(8, (total + 31) / 32) : 0;
+        if (!a.kgroup) { launch_dma_g<BN, PREC, 0, 0, 0>(a, grid, 1, s); return; }
+        const int groups = (total + a.kgroup - 1) / a.kgroup;
+        const size_t slot_bytes = (size_t)512 * (BN / 64) * 2 * 16 * sizeof(float);
+        const bool split = grid <= 96 && grid <= a.kcounter_n && (size_t)grid * groups * slot_bytes <= a.kscratch_bytes;
+        launch_dma_g<BN, PREC, 0, 0, 1>(a, grid, split ? groups : 1, s);
+    }
 }
 
 void launch_conv_igemm_dma(const ConvArgs& a, hipStream_t s) {

@@ -98,6 +98,11 @@ struct nhans_ctx {
     // workspace
     char* ws = nullptr;
     size_t ws_bytes = 0, ws_top = 0;
+    // split-K scratch of the conv kernel (small launches only)
+    float* kscratch = nullptr;
+    size_t kscratch_bytes = (size_t)64 << 20;
+    int* kcounter = nullptr;
+    int kcounter_n = 1024;
     int64_t frames_per_chunk = 1024;
     int contexts_per_chunk = 64;
     // pinned staging ring for the small host tables (offsets, block lists) copied per call
@@ -199,6 +204,7 @@ void fill_epilogue_defaults(nhans_ctx* c, ConvArgs& a) {
     a.prec = c->prec; a.out_split = c->prec; a.id_split = 0; a.ws = nullptr;
     a.variant = c->conv_variant >= 0 ? c->conv_variant : (c->prec == 1 ? 2 : 0);
     a.dbg = c->dbg;
+    a.kscratch = c->kscratch; a.kscratch_bytes = c->kscratch_bytes; a.kcounter = c->kcounter; a.kcounter_n = c->kcounter_n; a.kgroup = 0;
 }
 
 ConvSeg make_seg(const float* src, const float* wpk, int H, int W, int C, int KH, int KW, int sh, int sw,
@@ -255,6 +261,7 @@ int embed_impl(nhans_ctx* c, const float* ctx_lm, int n, float* emb_out, float* 
                 set_out_geometry(a, nc, g.hout, g.wout, g.cout, g.cout, g.cout, a1);
                 a.cb = c->A(p + ".c1.cb");
                 a.ws = c->WS(p + ".c1");
+                a.kgroup = -1;                  // a handful of context images: grouped sum, split-K when small
                 run_conv(c, a, s);
             }
             ConvArgs a{};
@@ -419,6 +426,7 @@ int mask_net_impl(nhans_ctx* c, const float* logmag, const int64_t* foff, int nc
         a.relu = 0;
         a.id_mode = 1; a.id = logmag + g0 * kBins; a.id_ld = kBins; a.idw = c->A("head.dense.idw");
         if (logits) { a.aux = logits + g0 * kBins; a.aux_ld = kBins; }
+        a.kgroup = -1;                          // K = 13312 over a few hundred frames: grouped sum, split-K when small
         run_conv(c, a, s);
     }
     return NHANS_OK;
@@ -536,6 +544,10 @@ int nhans_create(int model_kind, const void* blob, size_t nbytes, int device_id,
     if (e != hipSuccess) { nhans_destroy(c); return fail(NHANS_EHIP, "weight upload failed"); }
     e = hipHostMalloc(reinterpret_cast<void**>(&c->pin), c->pin_bytes, hipHostMallocDefault);
     if (e != hipSuccess) { nhans_destroy(c); return fail(NHANS_ENOMEM, "pinned staging allocation failed"); }
+    e = hipMalloc(reinterpret_cast<void**>(&c->kscratch), c->kscratch_bytes);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&c->kcounter), c->kcounter_n * sizeof(int));
+    if (e == hipSuccess) e = hipMemset(c->kcounter, 0, c->kcounter_n * sizeof(int));
+    if (e != hipSuccess) { nhans_destroy(c); return fail(NHANS_ENOMEM, "split-K scratch allocation failed"); }
     const BlobEntry* ent = reinterpret_cast<const BlobEntry*>(static_cast<const char*>(blob) + sizeof(BlobHeader));
     for (uint32_t i = 0; i < h->n_entries; ++i) {
         if (ent[i].offset % 16 || ent[i].offset + ent[i].nfloats * 4 > nbytes) {
@@ -597,6 +609,8 @@ void nhans_destroy(nhans_ctx* c) {
     for (auto& kv : c->prof)
         for (auto& ev : kv.second.pending) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     if (c->ws) (void)hipFree(c->ws);
+    if (c->kscratch) (void)hipFree(c->kscratch);
+    if (c->kcounter) (void)hipFree(c->kcounter);
     if (c->pin) (void)hipHostFree(c->pin);
     if (c->blob_dev) (void)hipFree(c->blob_dev);
     delete c;

@@ -74,6 +74,14 @@ struct ConvArgs {
     long long* dbg;        // optional (dev tool): 4 s_memtime stamps per workgroup [start, loop, epilogue, end]
     FastDiv fdHoWo, fdWo;
     FastDiv fdWP;          // Wo + KW - 1 (filled in by launch_conv_igemm_halo)
+    // split-K scratch (conv_igemm_dma.hip; null = never split): partial accumulator tiles and one
+    // zero-initialised ticket counter per output tile
+    float* kscratch;
+    size_t kscratch_bytes;
+    int* kcounter;
+    int kcounter_n;
+    int kgroup;            // caller: -1 = this layer may use grouped summation / split-K, 0 = never;
+                           // the launcher turns -1 into the chunks per group
 };
 
 // returns algorithmic FLOPs of the launch (2*M*K*Nreal)
