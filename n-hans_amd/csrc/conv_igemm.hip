@@ -341,7 +341,9 @@ double launch_conv_igemm(const ConvArgs& a, hipStream_t s) {
     double k = 0;
     for (int i = 0; i < a.nseg; ++i) k += (double)a.seg[i].nchunks * BK;
     if (a.variant >= 1) {
-        if (a.variant == 2 && conv_igemm_halo_eligible(a)) launch_conv_igemm_halo(a, s);
+        // (layers marked for grouped summation / split-K always take the LDS-DMA kernel, whatever the
+        // launch size: the choice must not depend on the batch)
+        if (a.variant == 2 && a.kgroup >= 0 && conv_igemm_halo_eligible(a)) launch_conv_igemm_halo(a, s);
         else launch_conv_igemm_dma(a, s);
         return 2.0 * (double)a.M * k * (double)a.Nreal;
     }

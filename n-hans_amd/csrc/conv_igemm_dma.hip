@@ -242,9 +242,15 @@ __global__ void __launch_bounds__(512) conv_igemm_dma(const ConvArgs a) {
     long long t_loop = 0, t_epi = 0;
     NH_ENTER_SEGMENT(0)
     if (cbeg) {                                        // cursor to chunk cbeg: K order (row, chunk, column)
+        int cb_ = cbeg;
+        if (cb_ >= n0chunks) {                         // the group starts inside the transform segment
+            cb_ -= n0chunks;
+            seg = 1;
+            NH_ENTER_SEGMENT(1)
+        }
         const int per_kh = (sC >> 5) * sKW;
-        kh = cbeg / per_kh;
-        const int r_ = cbeg - kh * per_kh;
+        kh = cb_ / per_kh;
+        const int r_ = cb_ - kh * per_kh;
         const int cc_ = r_ / sKW;
         kw = r_ - cc_ * sKW;
         c0 = cc_ * DBK;
@@ -456,9 +462,10 @@ static void launch_dma_t(const ConvArgs& a0, hipStream_t s) {
         // grid x groups accumulator tiles (512 threads x TM*TN*16 floats); any other launch walks the
         // groups in order inside the K loop.  Same additions in the same order either way.
         ConvArgs a = a0;
-        const int total = a.seg[0].nchunks;
+        int total = 0;
+        for (int i = 0; i < a.nseg; ++i) total += a.seg[i].nchunks;
         // (a.kgroup < 0 on entry = the caller marks the layers whose launches can be that small)
-        a.kgroup = (a0.kgroup < 0 && a.nseg == 1 && total >= 32 && a.kscratch && a.kcounter) ? std::max(8, (total + 31) / 32) : 0;
+        a.kgroup = (a0.kgroup < 0 && total >= 32 && a.kscratch && a.kcounter) ? std::max(8, (total + 31) / 32) : 0;
         if (!a.kgroup) { launch_dma_g<BN, PREC, 0, 0, 0>(a, grid, 1, s); return; }
         const int groups = (total + a.kgroup - 1) / a.kgroup;
         const size_t slot_bytes = (size_t)512 * (BN / 64) * 2 * 16 * sizeof(float);

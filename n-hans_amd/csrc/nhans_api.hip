@@ -278,7 +278,7 @@ int embed_impl(nhans_ctx* c, const float* ctx_lm, int n, float* emb_out, float* 
             set_out_geometry(a, nc, g.hout, g.wout, g.cout, g.cout, g.cout, y);
             a.cb = c->A(p + ".c2.cb");
             a.ws = c->WS(p + ".c2");
-            run_conv(c, a, s);
+            run_conv(c, a, s);                  // (stride 1: halo kernel; measured faster than split-K here)
             std::swap(x, y);
         }
         const BlockGeo& g = T[3];
