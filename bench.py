@@ -139,6 +139,18 @@ def main():
         dt = float(t.item())
 
     if rank == 0:
+        # HBM bytes per conv launch: PMC counters cannot be read from inside this process; the committed
+        # summary of the separate rocprofv3 --pmc passes over this very command (profiles/r01, README
+        # there) is quoted when the workload is the one it was collected on.
+        traffic, traffic_src = None, None
+        pmc = os.path.join(ROOT, "profiles", "r01", "pmc_summary_bench_f16x3_1step.json")
+        if a.precision == "f16x3" and a.clips_per_gpu == 1 and a.seconds == 10.0 and a.kind == "denoiser" and os.path.exists(pmc):
+            rows = [v for k, v in json.load(open(pmc)).items() if "conv_igemm" in k]
+            n = sum(v.get("dispatches_pass_c", 0) for v in rows)
+            if n:
+                traffic = sum((v.get("derived_hbm_read_bytes_per_launch", 0.0) + v.get("derived_hbm_write_bytes_per_launch", 0.0))
+                              * v.get("dispatches_pass_c", 0) for v in rows) / n
+                traffic_src = "profiles/r01/pmc_summary_bench_f16x3_1step.json (FETCH_SIZE x2 + WRITE_SIZE, bytes per conv launch)"
         kname = "conv_igemm_h3" if a.precision == "f16x3" else "conv_igemm_f32"
         peak = F16_MFMA_PEAK_TFLOPS if a.precision == "f16x3" else F32_MFMA_PEAK_TFLOPS
         conv = prof.get(kname, {"ms": 0.0, "flops": 0.0, "calls": 0})
@@ -162,7 +174,7 @@ def main():
             "frames_per_s": world * frames * a.steps / dt,
             "x_realtime_per_gpu": audio_s * a.steps / dt,
             "roofline": {"bound": "mfma", "kernel": kname, "achieved": tflops, "peak": peak,
-                         "unit": "TFLOP/s", "frac": tflops / peak, "traffic": None,
+                         "unit": "TFLOP/s", "frac": tflops / peak, "traffic": traffic, "traffic_source": traffic_src,
                          "launches": conv["calls"], "kernel_ms_per_step": conv["ms"] / a.steps,
                          "executed_tflops": tflops * (3 if a.precision == "f16x3" else 1)},
             "hbm_kernels": {"stft_features_GBs": gbs(stft), "istft_ola_GBs": gbs(istft), "peak_GBs": HBM_PEAK_GBS},
