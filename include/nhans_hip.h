@@ -71,7 +71,13 @@ void nhans_destroy(nhans_ctx* ctx);
  *          "profile" (1: time every kernel launch with hipEvents on the launch stream),
  *          "precision" (0: exact f32 matrix-core path, default; 1: split-f16 x3 -- every operand is
  *           carried as hi+lo f16 and multiplied with three f16 MFMAs into an f32 accumulator;
- *           FP32-class accuracy, activations must stay below the f16 range 65504). */
+ *           FP32-class accuracy, activations must stay below the f16 range 65504),
+ *          "conv_variant" (-1: automatic, default; 0: register-staged 128-pixel kernel; 1: LDS-DMA
+ *           256-pixel kernel; 2: halo-reuse kernel with producer/consumer waves where the conv
+ *           allows it, else 1 -- same results within rounding, different speed),
+ *          "debug_cycles_ptr" (developer tool: device address for per-workgroup cycle stamps).
+ * Besides the workspace a context holds 64 MB of split-K scratch for the few launches that are
+ * too small to fill the chip (the head's dense layer, the embedding tower at a few clips). */
 int nhans_set_option(nhans_ctx* ctx, const char* key, int64_t value);
 
 /* Bytes of device workspace the context would hold for a batch of this shape. */
