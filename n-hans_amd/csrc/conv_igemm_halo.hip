@@ -63,6 +63,8 @@ __global__ void __launch_bounds__((NCW + NPW) * 64) conv_igemm_halo(const ConvAr
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    long long dbg_entry = 0;
+    if constexpr (DBG) dbg_entry = (long long)__builtin_amdgcn_s_memtime();
 
     // XCD-aware, bijective remap of the linear workgroup id
     const int ntn = a.N / BN;
@@ -361,15 +363,22 @@ __global__ void __launch_bounds__((NCW + NPW) * 64) conv_igemm_halo(const ConvAr
     if constexpr (DBG) {                                // one record per wave
         if (a.dbg && lane == 0) {
             long long* d = a.dbg + ((size_t)blockIdx.x * (NCW + NPW) + wave) * 4;
-            d[0] = (long long)__builtin_amdgcn_s_memtime() - dbg_t0; d[1] = 0; d[2] = 0; d[3] = dbg_bar;
+            d[0] = (long long)__builtin_amdgcn_s_memtime() - dbg_t0; d[1] = dbg_t0 - dbg_entry; d[2] = 0; d[3] = dbg_bar;
         }
     }
 #undef NH_READ_HALF
 #undef NH_MFMA_HALF
 #undef NH_NEXT_TAP
 
+    long long dbg_epi = 0;
+    if constexpr (DBG) dbg_epi = (long long)__builtin_amdgcn_s_memtime();
     static_assert(conv_epilogue_lds_bytes<HBM, BN>() <= (size_t)(2 * A_BUF + BST * B_STAGE) * sizeof(float), "epilogue LDS");
     conv_epilogue<TM, TN, PREC, NCW * 64, HBM, BN>(a, acc, smem, m0, wm * 64, wn * TN * 32, nt * BN, tid, lane);
+    if constexpr (DBG) {                                // [.., prologue cycles, epilogue cycles, ..]
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (a.dbg && lane == 0)
+            a.dbg[((size_t)blockIdx.x * (NCW + NPW) + wave) * 4 + 2] = (long long)__builtin_amdgcn_s_memtime() - dbg_epi;
+    }
 }
 
 template <int BN, int PREC, int DBG = 0, int ABL = 0> static void launch_halo_t(const ConvArgs& a, hipStream_t s) {

@@ -37,7 +37,8 @@ def main():
     m = d.mean(0) / taps
     print("block %d conv2, %d taps, %d workgroups; cycles per tap" % (block, taps, nblk))
     for w in range(8):
-        print("  consumer wave %d: loop %.0f | lgkm+barrier %.0f | reads+MFMA %.0f" % (w, m[w, 0], m[w, 3], m[w, 0] - m[w, 3]))
+        print("  consumer wave %d: loop %.0f | lgkm+barrier %.0f | reads+MFMA %.0f   || per workgroup: prologue %.0f, K loop %.0f, epilogue %.0f cycles"
+              % (w, m[w, 0], m[w, 3], m[w, 0] - m[w, 3], m[w, 1] * taps, m[w, 0] * taps, m[w, 2] * taps))
     for w in range(8, 12):
         print("  producer wave %d: loop %.0f | DMA issue %.0f | vmcnt wait %.0f | barrier %.0f" % (w, m[w, 0], m[w, 1], m[w, 2], m[w, 3]))
 
