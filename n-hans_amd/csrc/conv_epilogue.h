@@ -33,13 +33,29 @@ template <int BMROWS, int BNCOLS> constexpr size_t conv_epilogue_lds_bytes() {
     return (size_t)BMROWS * (BNCOLS + 4) * sizeof(float) + (size_t)BMROWS * sizeof(int4);
 }
 
+// Tile-local pixel p -> global output pixel m (or -1 for a slot outside the tensor).
+struct EpiTile {
+    int m0;                 // linear tiles (tw == 0): pixel m0 + p
+    int tw, th;             // 2-D tiles: p = r*tw + c (r < th) is row r0+r, column c0+c of image b
+    int b, r0, c0;
+    __device__ __forceinline__ int operator()(int p, const ConvArgs& a) const {
+        if (tw <= 0) {
+            const int m = m0 + p;
+            return m < a.M ? m : -1;
+        }
+        const int r = p / tw, c = p - r * tw;
+        if (r >= th || r0 + r >= a.Ho || c0 + c >= a.Wo) return -1;
+        return (b * a.Ho + r0 + r) * a.Wo + c0 + c;
+    }
+};
+
 // Row-major sweep of the epilogue for one thread = (pixel row within a pass, 4 channels n..n+3).
 // IDM: 0 none, 1 split-NHWC tensor, 2 f32 tensor, 3 one-channel image; OUTS: split-NHWC output.
 // Passes are processed in groups: every load of a group is issued before its first store, so a group
 // costs one memory round trip (the residual may alias the output -- identity blocks are written in
 // place -- which would otherwise force the compiler to finish pass p before starting pass p+1).
 template <int PREC, int IDM, int OUTS, int PP, int PASSES, int LDC>
-__device__ __forceinline__ void conv_epilogue_sweep(const ConvArgs& a, const float* ct, const int4* rowinfo, int m0,
+__device__ __forceinline__ void conv_epilogue_sweep(const ConvArgs& a, const float* ct, const int4* rowinfo,
                                                     int prow, int c4, int n) {
     constexpr int GP = PASSES < 8 ? PASSES : 8;
     static_assert(PASSES % GP == 0, "pass grouping");
@@ -57,9 +73,8 @@ __device__ __forceinline__ void conv_epilogue_sweep(const ConvArgs& a, const flo
 #pragma unroll
         for (int u = 0; u < GP; ++u) {
             const int p = (pg + u) * PP + prow;
-            const int m = m0 + p;
-            const int mc = m < a.M ? m : a.M - 1;
-            const int4 ri = rowinfo[p];
+            const int4 ri = rowinfo[p];                       // (clip*cb_stride, (ho*Wo+wo)*N, m or -1, ids)
+            const int mc = ri.z < 0 ? 0 : ri.z;
             const f32x4 av = *reinterpret_cast<const f32x4*>(ct + p * LDC + c4 * 4);
             const f32x4 c = *reinterpret_cast<const f32x4*>(cbp + ri.x + n);
             const f32x4 t = *reinterpret_cast<const f32x4*>(tfp + (ri.y + n) * f_tf);
@@ -81,9 +96,9 @@ __device__ __forceinline__ void conv_epilogue_sweep(const ConvArgs& a, const flo
         }
 #pragma unroll
         for (int u = 0; u < GP; ++u) {
-            const int m = m0 + (pg + u) * PP + prow;
+            const int m = rowinfo[(pg + u) * PP + prow].z;
             const f32x4 y = yv[u];
-            if (m < a.M) {
+            if (m >= 0) {
                 if constexpr (OUTS) {
                     f16x4 h, l;
                     float yc;
@@ -106,7 +121,7 @@ __device__ __forceinline__ void conv_epilogue_sweep(const ConvArgs& a, const flo
 // (row_base, col_base); n_tile0: first channel of the workgroup tile; the caller has passed a
 // workgroup barrier after its last LDS read of the K loop.
 template <int TM, int TN, int PREC, int NTHREADS, int BMROWS, int BNCOLS>
-__device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[TM][TN], float* smem, int m0,
+__device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[TM][TN], float* smem, EpiTile tile,
                                               int row_base, int col_base, int n_tile0, int tid, int lane) {
     constexpr int LDC = BNCOLS + 4;
     constexpr int C4 = BNCOLS / 4;                    // threads along the channels of one pixel
@@ -128,15 +143,15 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[T
             }
     // 2. per-pixel (clip, h, w, 1-channel residual index)
     if (tid < BMROWS) {
-        int m = m0 + tid;
-        if (m >= a.M) m = a.M - 1;
+        const int mz = tile(tid, a);
+        const int m = mz < 0 ? 0 : mz;
         const uint32_t b = fd_div((uint32_t)m, a.fdHoWo);
         const uint32_t rem = (uint32_t)m - b * a.fdHoWo.d;
         const uint32_t ho = fd_div(rem, a.fdWo);
         const uint32_t wo = rem - ho * a.fdWo.d;
         const int clip = a.img_clip ? a.img_clip[b] : 0;
         const int ids = (int)((b * a.idH + ho * a.idsh) * a.idW + wo * a.idsw);
-        rowinfo[tid] = make_int4(clip * a.cb_stride, (int)rem * a.N, 0, ids);
+        rowinfo[tid] = make_int4(clip * a.cb_stride, (int)rem * a.N, mz, ids);
     }
     __syncthreads();
 
@@ -154,22 +169,22 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[T
         // straight-line block per group of passes, so all its loads issue before the first wait
         const int mode = (a.id_mode == 1 ? (id_split ? 1 : 2) : a.id_mode == 2 ? 3 : 0) * 2 + (a.out_split ? 1 : 0);
         switch (mode) {
-            case 0: conv_epilogue_sweep<PREC, 0, 0, PP, PASSES, LDC>(a, ct, rowinfo, m0, prow, c4, n); break;
-            case 1: conv_epilogue_sweep<PREC, 0, 1, PP, PASSES, LDC>(a, ct, rowinfo, m0, prow, c4, n); break;
-            case 2: conv_epilogue_sweep<PREC, 1, 0, PP, PASSES, LDC>(a, ct, rowinfo, m0, prow, c4, n); break;
-            case 3: conv_epilogue_sweep<PREC, 1, 1, PP, PASSES, LDC>(a, ct, rowinfo, m0, prow, c4, n); break;
-            case 4: conv_epilogue_sweep<PREC, 2, 0, PP, PASSES, LDC>(a, ct, rowinfo, m0, prow, c4, n); break;
-            case 5: conv_epilogue_sweep<PREC, 2, 1, PP, PASSES, LDC>(a, ct, rowinfo, m0, prow, c4, n); break;
-            case 6: conv_epilogue_sweep<PREC, 3, 0, PP, PASSES, LDC>(a, ct, rowinfo, m0, prow, c4, n); break;
-            default: conv_epilogue_sweep<PREC, 3, 1, PP, PASSES, LDC>(a, ct, rowinfo, m0, prow, c4, n); break;
+            case 0: conv_epilogue_sweep<PREC, 0, 0, PP, PASSES, LDC>(a, ct, rowinfo, prow, c4, n); break;
+            case 1: conv_epilogue_sweep<PREC, 0, 1, PP, PASSES, LDC>(a, ct, rowinfo, prow, c4, n); break;
+            case 2: conv_epilogue_sweep<PREC, 1, 0, PP, PASSES, LDC>(a, ct, rowinfo, prow, c4, n); break;
+            case 3: conv_epilogue_sweep<PREC, 1, 1, PP, PASSES, LDC>(a, ct, rowinfo, prow, c4, n); break;
+            case 4: conv_epilogue_sweep<PREC, 2, 0, PP, PASSES, LDC>(a, ct, rowinfo, prow, c4, n); break;
+            case 5: conv_epilogue_sweep<PREC, 2, 1, PP, PASSES, LDC>(a, ct, rowinfo, prow, c4, n); break;
+            case 6: conv_epilogue_sweep<PREC, 3, 0, PP, PASSES, LDC>(a, ct, rowinfo, prow, c4, n); break;
+            default: conv_epilogue_sweep<PREC, 3, 1, PP, PASSES, LDC>(a, ct, rowinfo, prow, c4, n); break;
         }
     } else {
         // ragged output (last_dense: 201 of 256 columns, unaligned rows, optional pre-residual tap)
         for (int ps = 0; ps < PASSES; ++ps) {
             const int p = ps * PP + prow;
-            const int m = m0 + p;
-            if (m >= a.M) continue;
             const int4 ri = rowinfo[p];
+            const int m = ri.z;
+            if (m < 0) continue;
             const float idsv = a.id_mode == 2 ? a.id[ri.w] : 0.f;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {

@@ -320,7 +320,7 @@ __global__ void __launch_bounds__(256) conv_igemm(const ConvArgs a) {
 
     // ---- epilogue (conv_epilogue.h): transposed through LDS, coalesced on the global side
     static_assert(conv_epilogue_lds_bytes<BM, BN>() <= (2 * BM * LDA + 2 * BK * BN) * sizeof(float), "epilogue LDS");
-    conv_epilogue<TM, TN, PREC, 256, BM, BN>(a, acc, smem, m0, wm * TM * 32, wn * TN * 32, nt * BN, tid, lane);
+    conv_epilogue<TM, TN, PREC, 256, BM, BN>(a, acc, smem, EpiTile{m0, 0, 0, 0, 0, 0}, wm * TM * 32, wn * TN * 32, nt * BN, tid, lane);
 }
 
 template <int BN, int WM, int WN, int PREC, int ABL = 0>

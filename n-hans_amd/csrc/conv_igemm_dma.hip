@@ -425,7 +425,7 @@ __global__ void __launch_bounds__(512) conv_igemm_dma(const ConvArgs a) {
         if (chk == 123.456f) a.out[0] = chk;
     } else {
         static_assert(conv_epilogue_lds_bytes<DBM, BN>() <= (size_t)DSTAGES * STAGE * sizeof(float), "epilogue LDS");
-        conv_epilogue<TM, TN, PREC, 512, DBM, BN>(a, acc, smem, m0, wm * 64, wn * TN * 32, nt * BN, tid, lane);
+        conv_epilogue<TM, TN, PREC, 512, DBM, BN>(a, acc, smem, EpiTile{m0, 0, 0, 0, 0, 0}, wm * 64, wn * TN * 32, nt * BN, tid, lane);
     }
     if (a.dbg) {                                       // dev tool (tools/conv_phase_cycles.py)
         __syncthreads();

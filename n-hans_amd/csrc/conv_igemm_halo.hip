@@ -373,7 +373,7 @@ __global__ void __launch_bounds__((NCW + NPW) * 64) conv_igemm_halo(const ConvAr
     long long dbg_epi = 0;
     if constexpr (DBG) dbg_epi = (long long)__builtin_amdgcn_s_memtime();
     static_assert(conv_epilogue_lds_bytes<HBM, BN>() <= (size_t)(2 * A_BUF + BST * B_STAGE) * sizeof(float), "epilogue LDS");
-    conv_epilogue<TM, TN, PREC, NCW * 64, HBM, BN>(a, acc, smem, m0, wm * 64, wn * TN * 32, nt * BN, tid, lane);
+    conv_epilogue<TM, TN, PREC, NCW * 64, HBM, BN>(a, acc, smem, EpiTile{m0, 0, 0, 0, 0, 0}, wm * 64, wn * TN * 32, nt * BN, tid, lane);
     if constexpr (DBG) {                                // [.., prologue cycles, epilogue cycles, ..]
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (a.dbg && lane == 0)
