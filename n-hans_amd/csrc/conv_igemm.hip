@@ -343,7 +343,9 @@ double launch_conv_igemm(const ConvArgs& a, hipStream_t s) {
     if (a.variant >= 1) {
         // (layers marked for grouped summation / split-K always take the LDS-DMA kernel, whatever the
         // launch size: the choice must not depend on the batch)
-        if (a.variant == 2 && a.kgroup >= 0 && conv_igemm_halo_eligible(a)) launch_conv_igemm_halo(a, s);
+        if (a.variant == 2 && a.kgroup >= 0 && launch_conv_igemm_halo2d(a, s)) {
+            // 2-D pixel tiles: the 64-channel stride-1 convs
+        } else if (a.variant == 2 && a.kgroup >= 0 && conv_igemm_halo_eligible(a)) launch_conv_igemm_halo(a, s);
         else launch_conv_igemm_dma(a, s);
         return 2.0 * (double)a.M * k * (double)a.Nreal;
     }

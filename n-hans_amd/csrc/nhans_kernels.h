@@ -82,6 +82,9 @@ struct ConvArgs {
     int kcounter_n;
     int kgroup;            // caller: -1 = this layer may use grouped summation / split-K, 0 = never;
                            // the launcher turns -1 into the chunks per group
+    // 2-D pixel tiles (conv_igemm_halo2d.hip; filled in by its launcher): th x tw output pixels of one
+    // image per workgroup, ntr x ntc tiles per image
+    int t2_th, t2_tw, t2_ntr, t2_ntc;
 };
 
 // returns algorithmic FLOPs of the launch (2*M*K*Nreal)
@@ -89,6 +92,7 @@ double launch_conv_igemm(const ConvArgs& a, hipStream_t s);
 void launch_conv_igemm_dma(const ConvArgs& a, hipStream_t s);   // conv_igemm_dma.hip
 bool conv_igemm_halo_eligible(const ConvArgs& a);               // conv_igemm_halo.hip
 void launch_conv_igemm_halo(const ConvArgs& a, hipStream_t s);
+bool launch_conv_igemm_halo2d(const ConvArgs& a, hipStream_t s);  // conv_igemm_halo2d.hip; false = not eligible, nothing launched
 
 // ---------------------------------------------------------------------------------------------
 // Small kernels (aux_kernels.hip)
