@@ -11,8 +11,11 @@
 //     no ds_write pass, no select for padding -- padded taps read a zero page, resolved once per
 //     filter tap into per-row pointers.
 //   * The LDS-DMA destination is lane-linear, so the A image cannot be padded against bank
-//     conflicts; it is XOR-swizzled instead (16-byte piece p of pixel row r sits at slot p^(r&7)),
-//     applied on the SOURCE address of the DMA and on the ds_read address (2-way worst case).
+//     conflicts; it is XOR-swizzled instead (16-byte piece p of pixel row r sits at slot
+//     p^((r>>1)&7): two 128-byte rows share a 256-byte bank row, and a ds_read_b128 lane group covers
+//     rows {r..r+3, r+12..r+15, r+20..r+27} -- with (r>>1)&7 its 16 slots are distinct; the obvious
+//     r&7 is 2-way conflicted and measured 18 % slower in tools/ubench/consumer_loop.hip), applied on
+//     the SOURCE address of the DMA and on the ds_read address.
 //   * 3-stage LDS ring, prefetch distance 2: iteration `it` issues the DMA of chunk it+2, multiplies
 //     chunk it, then waits with a COUNTED `s_waitcnt vmcnt(G)` (G = DMA instructions per chunk) so
 //     that chunk it+1 has landed while chunk it+2 stays in flight across the raw `s_barrier`.
@@ -71,7 +74,7 @@ __global__ void __launch_bounds__(512) conv_igemm_dma(const ConvArgs a) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int row = j * 64 + wave * 8 + (lane >> 3);
-        spiece[j] = (slot ^ (row & 7)) * 4;           // float offset of the source piece
+        spiece[j] = (slot ^ ((row >> 1) & 7)) * 4;    // float offset of the source piece
         const int m = m0 + row;
         if (m < a.M) {
             const uint32_t b = fd_div((uint32_t)m, a.fdHoWo);
@@ -162,7 +165,7 @@ __global__ void __launch_bounds__(512) conv_igemm_dma(const ConvArgs a) {
     int aoff[TM];
 #pragma unroll
     for (int t = 0; t < TM; ++t) aoff[t] = (wm * 64 + t * 32 + (lane & 31)) * 32;
-    const int rsw = lane & 7;                          // (row & 7): tile rows start at multiples of 32
+    const int rsw = (lane >> 1) & 7;                   // ((row>>1) & 7): tile rows start at multiples of 32
     const int bcol = A_STAGE + (wn * TN) * 1024 + lane * 4;
 
     // MFMA operands of one whole chunk live in registers between the two phases

@@ -34,9 +34,19 @@ constexpr int T2_NPW = 4;      // producer (DMA) waves
 template <int N> __device__ __forceinline__ void t2_wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
+
+// scheduling pattern of a consumer half: one MFMA, then the LDS reads' even share (0x008 MFMA, 0x100 DS read)
+template <int I, int NM, int ND> __device__ __forceinline__ void t2_interleave() {
+    if constexpr (I < NM) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        constexpr int nd = (I + 1) * ND / NM - I * ND / NM;
+        if constexpr (nd > 0) __builtin_amdgcn_sched_group_barrier(0x100, nd, 0);
+        t2_interleave<I + 1, NM, ND>();
+    }
+}
 }  // namespace
 
-template <int BN, int PREC, int HR2>
+template <int BN, int PREC, int HR2, int ABL = 0>   // ABL 1: no per-tap barrier (timing experiment, wrong results)
 __global__ void __launch_bounds__((T2_NCW + T2_NPW) * 64) conv_igemm_halo2d(const ConvArgs a) {
     constexpr int TM = 2;
     constexpr int TN = BN / 64;
@@ -152,7 +162,7 @@ __global__ void __launch_bounds__((T2_NCW + T2_NPW) * 64) conv_igemm_halo2d(cons
             NH_ISSUE_B((it + 3) & (T2_BST - 1))
             if (first || prev_first) t2_wait_vmcnt<2 * GBP + NAP>();
             else t2_wait_vmcnt<2 * GBP>();
-            __builtin_amdgcn_s_barrier();
+            if constexpr (!(ABL & 1)) __builtin_amdgcn_s_barrier();
             prev_first = first;
             NH_NEXT_TAP()
         }
@@ -231,20 +241,25 @@ __global__ void __launch_bounds__((T2_NCW + T2_NPW) * 64) conv_igemm_halo2d(cons
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[t][j][r] = 0.f;
 
+    constexpr int NM = KH_ * TM * TN * (PREC == 1 ? 3 : 4);         // MFMAs per half
+    constexpr int ND = KH_ * (TM + TN) * (PREC == 1 ? 2 : 1);       // ds_read_b128 per half
     __builtin_amdgcn_s_barrier();                       // image 0 and tap 0 have landed
     NH_READ_HALF(0, 0)
     for (int it = 0; it < total; ++it) {
-        NH_READ_HALF(1, it & (T2_BST - 1))
         __builtin_amdgcn_sched_barrier(0);
+        NH_READ_HALF(1, it & (T2_BST - 1))
+        if constexpr (!(ABL & 2)) __builtin_amdgcn_sched_barrier(0);
         NH_MFMA_HALF(0)
+        if constexpr ((ABL & 2) != 0) t2_interleave<0, NM, ND>();
         __builtin_amdgcn_sched_barrier(0);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
+        if constexpr (!(ABL & 1)) __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
         NH_NEXT_TAP()
         NH_READ_HALF(0, (it + 1) & (T2_BST - 1))        // (past the last tap: a harmless read)
-        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (!(ABL & 2)) __builtin_amdgcn_sched_barrier(0);
         NH_MFMA_HALF(1)
+        if constexpr ((ABL & 2) != 0) t2_interleave<0, NM, ND>();
         __builtin_amdgcn_sched_barrier(0);
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -276,16 +291,16 @@ bool plan_tiles(int Ho, int Wo, int KH, int KW, int rows, int* th_, int* tw_, do
     return best > 0;
 }
 
-template <int BN, int PREC> void launch_t2(const ConvArgs& a, int images, hipStream_t s) {
+template <int BN, int PREC, int ABL = 0> void launch_t2(const ConvArgs& a, int images, hipStream_t s) {
     constexpr size_t lds = (size_t)(2 * kHR2 * 32 + T2_BST * 32 * BN) * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_halo2d<BN, PREC, kHR2>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_halo2d<BN, PREC, kHR2, ABL>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
     const int grid = images * a.t2_ntr * a.t2_ntc * (a.N / BN);
-    hipLaunchKernelGGL((conv_igemm_halo2d<BN, PREC, kHR2>), dim3(grid), dim3((T2_NCW + T2_NPW) * 64), lds, s, a);
+    hipLaunchKernelGGL((conv_igemm_halo2d<BN, PREC, kHR2, ABL>), dim3(grid), dim3((T2_NCW + T2_NPW) * 64), lds, s, a);
 }
 }  // namespace
 
@@ -303,7 +318,11 @@ bool launch_conv_igemm_halo2d(const ConvArgs& a0, hipStream_t s) {
     ConvArgs a = a0;
     a.t2_th = th; a.t2_tw = tw;
     a.t2_ntr = (a.Ho + th - 1) / th; a.t2_ntc = (a.Wo + tw - 1) / tw;
-    if (a.prec == 1) launch_t2<64, 1>(a, images, s); else launch_t2<64, 0>(a, images, s);
+    static const int abl = [] { const char* e = getenv("NHANS_ABLATE"); return e ? atoi(e) : 0; }();
+    if (a.prec == 1 && abl == 512) launch_t2<64, 1, 1>(a, images, s);     // timing experiment: no per-tap barrier
+    else if (a.prec == 1 && abl == 1024) launch_t2<64, 1, 2>(a, images, s);   // reads interleaved 1:1 with the MFMAs
+    else if (a.prec == 1) launch_t2<64, 1>(a, images, s);
+    else launch_t2<64, 0>(a, images, s);
     return true;
 }
 
