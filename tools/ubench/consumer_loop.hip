@@ -7,7 +7,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
-template <int TN, int MODE, int BAR, int NW = 8, int SWZ = 0>   // SWZ 1: all lanes one row (no conflicts), 2: row&7 swizzle; MODE 0: reads + MFMAs, 1: MFMAs only, 2: reads only
+template <int TN, int MODE, int BAR, int NW = 8, int SWZ = 0, int ORD = 0>   // ORD 1: older wave of a SIMD issues MFMAs first, younger reads first; 2: all MFMAs first; SWZ 1: all lanes one row (no conflicts), 2: row&7 swizzle; MODE 0: reads + MFMAs, 1: MFMAs only, 2: reads only
 __global__ void __launch_bounds__(NW * 64) k(float* out, int taps, long long* cyc) {
     constexpr int TM = 2, KS = 2;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -53,18 +53,31 @@ __global__ void __launch_bounds__(NW * 64) k(float* out, int taps, long long* cy
     }
     const long long t0 = __builtin_amdgcn_s_memtime();
     RD(0, 0, 0)
+    const bool mfma_first = ORD == 2 || (ORD == 1 && wave < NW / 2);
     for (int it = 0; it < taps; ++it) {
         const int kw = it & 3;
-        RD(1, kw, it)
-        __builtin_amdgcn_sched_barrier(0);
-        MM(0)
+        if (mfma_first) {
+            MM(0)
+            __builtin_amdgcn_sched_barrier(0);
+            RD(1, kw, it)
+        } else {
+            RD(1, kw, it)
+            __builtin_amdgcn_sched_barrier(0);
+            MM(0)
+        }
         __builtin_amdgcn_sched_barrier(0);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if constexpr (BAR) __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
-        RD(0, (kw + 1) & 3, it + 1)
-        __builtin_amdgcn_sched_barrier(0);
-        MM(1)
+        if (mfma_first) {
+            MM(1)
+            __builtin_amdgcn_sched_barrier(0);
+            RD(0, (kw + 1) & 3, it + 1)
+        } else {
+            RD(0, (kw + 1) & 3, it + 1)
+            __builtin_amdgcn_sched_barrier(0);
+            MM(1)
+        }
         __builtin_amdgcn_sched_barrier(0);
     }
     const long long t1 = __builtin_amdgcn_s_memtime();
@@ -74,12 +87,12 @@ __global__ void __launch_bounds__(NW * 64) k(float* out, int taps, long long* cy
     if (lane == 0) cyc[blockIdx.x * 8 + wave] = t1 - t0;
 }
 
-template <int TN, int MODE, int BAR, int NW = 8, int SWZ = 0> void run(const char* what) {
+template <int TN, int MODE, int BAR, int NW = 8, int SWZ = 0, int ORD = 0> void run(const char* what) {
     const int blocks = 256, taps = 2000;
     float* out; long long* cyc;
     hipMalloc(&out, blocks * 512 * 4); hipMalloc(&cyc, blocks * 64);
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&k<TN, MODE, BAR, NW, SWZ>), hipFuncAttributeMaxDynamicSharedMemorySize, 147456);
-    for (int r = 0; r < 2; ++r) hipLaunchKernelGGL((k<TN, MODE, BAR, NW, SWZ>), dim3(blocks), dim3(NW * 64), 147456, 0, out, taps, cyc);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&k<TN, MODE, BAR, NW, SWZ, ORD>), hipFuncAttributeMaxDynamicSharedMemorySize, 147456);
+    for (int r = 0; r < 2; ++r) hipLaunchKernelGGL((k<TN, MODE, BAR, NW, SWZ, ORD>), dim3(blocks), dim3(NW * 64), 147456, 0, out, taps, cyc);
     hipDeviceSynchronize();
     long long h[2048]; hipMemcpy(h, cyc, sizeof h, hipMemcpyDeviceToHost);
     double c0 = 0, c4 = 0; for (int i = 0; i < 256; ++i) { c0 += h[i * 8]; c4 += h[i * 8 + (NW == 8 ? 4 : 3)]; }
@@ -89,11 +102,11 @@ template <int TN, int MODE, int BAR, int NW = 8, int SWZ = 0> void run(const cha
 }
 
 int main() {
-    run<1, 2, 0, 8, 0>("reads (row>>1)&7");
-    run<1, 2, 0, 8, 2>("reads row&7");
-    run<1, 2, 0, 8, 1>("reads broadcast");
-    run<2, 2, 0, 8, 0>("reads (row>>1)&7");
-    run<2, 2, 0, 8, 2>("reads row&7");
-    run<2, 2, 0, 8, 1>("reads broadcast");
+    run<1, 0, 1, 8, 0, 0>("reads first");
+    run<1, 0, 1, 8, 0, 1>("old MFMA first");
+    run<1, 0, 1, 8, 0, 2>("all MFMA first");
+    run<2, 0, 1, 8, 0, 0>("reads first");
+    run<2, 0, 1, 8, 0, 1>("old MFMA first");
+    run<2, 0, 1, 8, 0, 2>("all MFMA first");
     return 0;
 }
