@@ -163,26 +163,42 @@ void launch_avgpool(const float* x, int B, int HW, int C, int split, float* out,
 // ---------------------------------------------------------------------------------------------
 // All 16 conditioning projections of a clip at once (process_noise_t_f, SN/main.py:139-148), with
 // the BatchNorm scale/shift, conv bias and transform bias folded into Wc/base on the host.
+// Block = 64 columns x 4 slices of K; every thread keeps 4 independent partial sums so that 4 loads
+// are in flight, and the 16 partials of a column are added in a fixed order (deterministic, and the
+// same for any batch).  One clip is 60 blocks instead of 15 threads-with-1024-serial-loads.
 __global__ void __launch_bounds__(256) cond_kernel(const float* ea, const float* eb, const float* Wc,
                                                    const float* base, int ncols, float* cb) {
     __shared__ float e[2 * kEmb];
+    __shared__ float part[4][64];
     const int clip = blockIdx.x;
     for (int i = threadIdx.x; i < kEmb; i += 256) {
         e[i] = ea[(size_t)clip * kEmb + i];
         e[kEmb + i] = eb[(size_t)clip * kEmb + i];
     }
     __syncthreads();
-    const int n = blockIdx.y * 256 + threadIdx.x;
-    if (n >= ncols) return;
-    float acc = base[n];
-    for (int k = 0; k < 2 * kEmb; ++k) acc = fmaf(e[k], Wc[(size_t)k * ncols + n], acc);
-    cb[(size_t)clip * ncols + n] = acc;
+    const int col = threadIdx.x & 63, ks = threadIdx.x >> 6;
+    const int n = blockIdx.y * 64 + col;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    if (n < ncols) {
+        const int k0 = ks * (2 * kEmb / 4);
+        const float* w = Wc + (size_t)k0 * ncols + n;
+        for (int k = 0; k < 2 * kEmb / 4; k += 4) {
+            a0 = fmaf(e[k0 + k], w[(size_t)k * ncols], a0);
+            a1 = fmaf(e[k0 + k + 1], w[(size_t)(k + 1) * ncols], a1);
+            a2 = fmaf(e[k0 + k + 2], w[(size_t)(k + 2) * ncols], a2);
+            a3 = fmaf(e[k0 + k + 3], w[(size_t)(k + 3) * ncols], a3);
+        }
+    }
+    part[ks][col] = (a0 + a1) + (a2 + a3);
+    __syncthreads();
+    if (ks == 0 && n < ncols)
+        cb[(size_t)clip * ncols + n] = base[n] + ((part[0][col] + part[1][col]) + (part[2][col] + part[3][col]));
 }
 
 void launch_cond(const float* ea, const float* eb, int nclips, const float* Wc, const float* base, int ncols,
                  float* cb, hipStream_t s) {
     if (nclips <= 0) return;
-    hipLaunchKernelGGL(cond_kernel, dim3(nclips, (ncols + 255) / 256), dim3(256), 0, s, ea, eb, Wc, base, ncols, cb);
+    hipLaunchKernelGGL(cond_kernel, dim3(nclips, (ncols + 63) / 64), dim3(256), 0, s, ea, eb, Wc, base, ncols, cb);
 }
 
 }  // namespace nhans
