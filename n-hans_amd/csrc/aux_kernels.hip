@@ -63,6 +63,75 @@ __global__ void __launch_bounds__(256) direct_conv64(const DirectArgs a) {
     }
 }
 
+// The 4x4 case (resblock1_1_conv1: 7,035 pixels per frame-window, 4 % of a step when done by the
+// generic kernel above, whose 16 global loads per thread sit in a branchy loop): persistent blocks,
+// the thread's 16 x 4 weights live in registers, a block takes 4 x 16 output pixels at a time and
+// stages their zero-padded input patch in LDS once, so the inner loop is 16 LDS reads + 64 FMAs.
+// Same taps in the same order as the generic kernel (a padded tap adds 0 * w): bitwise the same.
+template <int SPLIT>
+__global__ void __launch_bounds__(256) direct_conv64_4x4(const DirectArgs a, int tiles_r, int tiles_c, int ntiles) {
+    __shared__ float patch[1024];
+    const int cq = threadIdx.x & 15, c = cq * 4, pc = threadIdx.x >> 4;
+    float4 w[16];
+#pragma unroll
+    for (int t = 0; t < 16; ++t) w[t] = *reinterpret_cast<const float4*>(a.w + t * 64 + c);
+    const int PH = 3 * a.sh + 4, PW = 15 * a.sw + 4;
+    const int tpi = tiles_r * tiles_c;
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int b = tile / tpi;
+        const int q = tile - b * tpi;
+        const int tr = q / tiles_c;
+        const int ho0 = tr * 4, wo0 = (q - tr * tiles_c) * 16;
+        const int hi0 = ho0 * a.sh - a.pt, wi0 = wo0 * a.sw - a.pl;
+        const float* img = a.src + (size_t)b * a.H * a.W;
+        __syncthreads();                                   // the previous tile's readers are done
+        for (int i = threadIdx.x; i < PH * PW; i += 256) {
+            const int ph = i / PW, pw = i - ph * PW;
+            const int hi = hi0 + ph, wi = wi0 + pw;
+            patch[i] = ((unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W) ? img[hi * a.W + wi] : 0.f;
+        }
+        __syncthreads();
+        const int clip = a.img_clip ? a.img_clip[b] : 0;
+        const float4 cb = *reinterpret_cast<const float4*>(a.cb + (size_t)clip * a.cb_stride + c);
+#pragma unroll 1
+        for (int pass = 0; pass < 4; ++pass) {
+            const int ho = ho0 + pass, wo = wo0 + pc;
+            if (ho >= a.Ho || wo >= a.Wo) continue;
+            const float* px = patch + (pass * a.sh) * PW + pc * a.sw;
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                const float x = px[(t >> 2) * PW + (t & 3)];
+                acc.x = fmaf(x, w[t].x, acc.x); acc.y = fmaf(x, w[t].y, acc.y);
+                acc.z = fmaf(x, w[t].z, acc.z); acc.w = fmaf(x, w[t].w, acc.w);
+            }
+            const int rem = ho * a.Wo + wo;
+            const size_t m = (size_t)b * a.Ho * a.Wo + rem;
+            acc.x += cb.x; acc.y += cb.y; acc.z += cb.z; acc.w += cb.w;
+            if (a.tf) {
+                const float4 t = *reinterpret_cast<const float4*>(a.tf + (size_t)rem * 64 + c);
+                acc.x += t.x; acc.y += t.y; acc.z += t.z; acc.w += t.w;
+            }
+            if (a.relu) {
+                acc.x = fmaxf(acc.x, 0.f); acc.y = fmaxf(acc.y, 0.f);
+                acc.z = fmaxf(acc.z, 0.f); acc.w = fmaxf(acc.w, 0.f);
+            }
+            if constexpr (SPLIT) {
+                typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+                h4 hi, lo;
+                hi.x = (_Float16)acc.x; hi.y = (_Float16)acc.y; hi.z = (_Float16)acc.z; hi.w = (_Float16)acc.w;
+                lo.x = (_Float16)(acc.x - (float)hi.x); lo.y = (_Float16)(acc.y - (float)hi.y);
+                lo.z = (_Float16)(acc.z - (float)hi.z); lo.w = (_Float16)(acc.w - (float)hi.w);
+                _Float16* line = reinterpret_cast<_Float16*>(a.out + m * 64) + (c >> 5) * 64 + (c & 31);
+                *reinterpret_cast<h4*>(line) = hi;
+                *reinterpret_cast<h4*>(line + 32) = lo;
+            } else {
+                *reinterpret_cast<float4*>(a.out + m * 64 + c) = acc;
+            }
+        }
+    }
+}
+
 __global__ void __launch_bounds__(256) unsplit_kernel(const float* src, int64_t total, int C, float* dst) {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
         const int64_t m = i / C;
@@ -81,6 +150,14 @@ void launch_unsplit(const float* src, int64_t M, int C, float* dst, hipStream_t 
 }
 
 void launch_direct_conv64(const DirectArgs& a, hipStream_t s) {
+    if (a.KH == 4 && a.KW == 4 && a.sh <= 3 && a.sw <= 3 && a.M % (a.Ho * a.Wo) == 0) {
+        const int tiles_r = (a.Ho + 3) / 4, tiles_c = (a.Wo + 15) / 16;
+        const int ntiles = (a.M / (a.Ho * a.Wo)) * tiles_r * tiles_c;
+        const int grid4 = ntiles < 256 * 8 ? ntiles : 256 * 8;
+        if (a.out_split) hipLaunchKernelGGL(direct_conv64_4x4<1>, dim3(grid4), dim3(256), 0, s, a, tiles_r, tiles_c, ntiles);
+        else hipLaunchKernelGGL(direct_conv64_4x4<0>, dim3(grid4), dim3(256), 0, s, a, tiles_r, tiles_c, ntiles);
+        return;
+    }
     int grid = (a.M + 15) / 16;
     if (grid > 256 * 16) grid = 256 * 16;
     hipLaunchKernelGGL(direct_conv64, dim3(grid), dim3(256), 0, s, a);
