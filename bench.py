@@ -78,6 +78,19 @@ def cpu_baseline(W, kind, mix, ca, cb, frames, hip_wav, threads):
            "sample": "first %d-frame minibatch of clip 0, float32 torch-CPU restatement in reference-faithful mode "
                      "(both 200-frame contexts tiled per frame, embedding towers re-run inside the minibatch, "
                      "SN/apply.py:381-387,440-446), %.1f s" % (n, dt)}
+    # the same port with the embeddings computed once per clip (the restructuring of SURVEY F7 that the
+    # HIP path also uses), extrapolated to the whole clip: separates that algorithmic saving from the hardware
+    with torch.no_grad():
+        lm = ref.features(mix)[0]
+        win = ref.windows(lm)[:frames]
+        t1 = time.time()
+        ea = ref.tower(ref.features(ca)[0][:spec.NOISE_WIN][None])
+        eb = ref.tower(ref.features(cb)[0][:spec.NOISE_WIN][None])
+        t_tower = time.time() - t1
+        t1 = time.time()
+        ref.mask_net(win, ea.expand(len(win), -1), eb.expand(len(win), -1))
+        t_batch = time.time() - t1
+    res["dedup_embedding_value"] = (len(mix) / float(spec.FS)) / (t_tower + lm.shape[0] / float(len(win)) * t_batch)
     # samples below (n-2)*160 depend only on frames < n
     k = max((n - 2) * spec.HOP, 0)
     cw = out["denoised_wav"].numpy()[:k]
