@@ -18,7 +18,13 @@
  * arrays.  `stream` is a hipStream_t (0 = default stream); all work is enqueued on it and the
  * functions do not synchronise.  The library owns only its context: folded weights and a
  * workspace that grows on demand.  One context per (device, model); a context is not
- * thread-safe, distinct contexts are independent.
+ * thread-safe, distinct contexts are independent (also on different devices of one process).
+ * Consecutive calls on one context share its workspace: the library orders them itself -- a call
+ * on another stream than the previous one first makes its stream wait (hipStreamWaitEvent) for the
+ * previous call's work -- so results never depend on the caller's choice of streams, but two calls
+ * on one context never overlap either; use one context per concurrent stream for that.
+ * A kernel launch the runtime rejects (invalid grid, LDS request, ...) is reported by the entry
+ * point that issued it as NHANS_EHIP, naming the kernel; nothing runs on unlaunched results.
  *
  * Ragged batches: clip c owns samples [sample_offsets[c], sample_offsets[c+1]) of the wav
  * buffer and frames [frame_offsets[c], frame_offsets[c+1]) of every [T_total, 201] tensor, with
@@ -35,7 +41,7 @@
 extern "C" {
 #endif
 
-#define NHANS_ABI_VERSION 1
+#define NHANS_ABI_VERSION 2
 
 #define NHANS_DENOISER 0   /* SN model: emb_a = positive context (--pos), emb_b = negative (--neg) */
 #define NHANS_SEPARATOR 1  /* SS model: emb_a = interferer  (--neg),      emb_b = target   (--pos) */
@@ -45,6 +51,11 @@ extern "C" {
 #define NHANS_EHIP (-2)     /* HIP runtime error */
 #define NHANS_ENOMEM (-3)   /* workspace allocation failed */
 #define NHANS_ESHORT (-4)   /* a conditioning recording yields fewer than 200 frames */
+
+/* sticky device-side status bits, see nhans_take_status() */
+#define NHANS_STATUS_SATURATED 1   /* precision 1: an activation did not fit the f16 range (|v| >= 65504 or NaN)
+                                      and was clamped -- the outputs of the calls since the last
+                                      nhans_take_status() are not trustworthy; rerun them with precision 0 */
 
 #define NHANS_WIN 400
 #define NHANS_HOP 160
@@ -74,8 +85,9 @@ void nhans_destroy(nhans_ctx* ctx);
  *           FP32-class accuracy, activations must stay below the f16 range 65504),
  *          "conv_variant" (-1: automatic, default; 0: register-staged 128-pixel kernel; 1: LDS-DMA
  *           256-pixel kernel; 2: halo-reuse kernel with producer/consumer waves where the conv
- *           allows it, else 1 -- same results within rounding, different speed),
- *          "debug_cycles_ptr" (developer tool: device address for per-workgroup cycle stamps).
+ *           allows it, else 1 -- same results within rounding, different speed).
+ * (A `make DEV=1` build adds "debug_cycles_ptr" and the NHANS_ABLATE / NHANS_HALO2D environment
+ * switches used by tools/; the default build has no developer hooks and reads no environment.)
  * Besides the workspace a context holds 64 MB of split-K scratch for the few launches that are
  * too small to fill the chip (the head's dense layer, the embedding tower at a few clips). */
 int nhans_set_option(nhans_ctx* ctx, const char* key, int64_t value);
@@ -125,6 +137,23 @@ int nhans_enhance_clips(nhans_ctx* ctx, const float* mix_wav_dev, const int64_t*
 int nhans_debug_block_output(nhans_ctx* ctx, const float* logmag_dev, const int64_t* frame_offsets_host,
                              int nclips, const float* emb_a_dev, const float* emb_b_dev,
                              int64_t frame0, int nframes, int block, float* out_dev, void* stream);
+
+/* Waits for `stream`, then returns the context's sticky status bits (NHANS_STATUS_*) in
+ * *flags_out and clears them.  The hot-path calls are asynchronous, so conditions detected on the
+ * device (split-f16 activation overflow) cannot be part of their return code; a caller that uses
+ * precision 1 on weights it has not validated calls this once per batch. */
+int nhans_take_status(nhans_ctx* ctx, int* flags_out, void* stream);
+
+/* Self-test of the launch-error path (needs no context): launches a trivial kernel on the current
+ * device with `dynamic_lds_bytes` of dynamic LDS.  Returns NHANS_OK if the launch was accepted,
+ * NHANS_EHIP (with the runtime's message in nhans_last_error()) if not -- e.g. for a request above
+ * the 160 KB a gfx950 CU has, or when no HIP device is present. */
+int nhans_debug_launch_probe(size_t dynamic_lds_bytes, void* stream);
+
+/* Host helper (no device involved): CRC-32C (Castagnoli) of a host buffer continued from `crc`
+ * (0 to start).  TensorFlow checkpoint bundles store crc32c::Mask() of it per tensor; tfbundle.py
+ * verifies the 116 MB data shard with it (BundleEntryProto field 6 of the reference's shipped trained_model .index files). */
+uint32_t nhans_crc32c(uint32_t crc, const void* data_host, size_t nbytes);
 
 /* Profiling (option "profile" = 1): per-kernel launch counts, summed milliseconds and summed
  * algorithmic FLOPs / bytes since the last reset, as a JSON object written to buf.  Synchronises

@@ -41,6 +41,7 @@ DENOISER_BUNDLE = "81448_0-1000000"      # SN/apply.py:431-432
 SEPARATOR_BUNDLE = "81457_2-545000"      # SS/apply.py:371-372
 
 _engines = {}
+_device_index = 0
 
 
 class Flags(object):
@@ -62,14 +63,14 @@ FLAGS = Flags()
 
 # ------------------------------------------------------------------------------ wav front end
 def read_wav(in_path):
-    """SN/apply.py:46-53."""
-    rate, samples = wavread(in_path)
-    assert rate == FLAGS.Fs
-    assert samples.dtype == 'int16'
-    if len(samples.shape) > 1:
-        samples = samples.mean(axis=1)
-    assert len(samples.shape) == 1
-    return samples
+    """Contract of the reference's reader (SN/apply.py:46-53): 16 kHz int16 PCM only, anything else
+    is an AssertionError; a multi-channel file comes back as the float64 mean of its channels."""
+    rate, pcm = wavread(in_path)
+    if rate != FLAGS.Fs:
+        raise AssertionError("%s: sample rate %d Hz, expected %d" % (in_path, rate, FLAGS.Fs))
+    if pcm.dtype != np.int16:
+        raise AssertionError("%s: sample format %s, expected int16" % (in_path, pcm.dtype))
+    return pcm if pcm.ndim == 1 else pcm.mean(axis=1)
 
 
 def read_wav_any(in_path):
@@ -110,12 +111,11 @@ def normalise(samples):
 
 
 def trim_to_frames(samples):
-    """Cut the end to have an exact number of frames (SN/apply.py:158-161)."""
-    win_samples = int(FLAGS.Fs * 0.025)
-    hop_samples = int(FLAGS.Fs * 0.010)
-    if (len(samples) - win_samples) % hop_samples != 0:
-        samples = samples[:-((len(samples) - win_samples) % hop_samples)]
-    return samples
+    """Drop the tail that does not fill a hop, so that the STFT covers every kept sample
+    (SN/apply.py:158-161).  Python's non-negative modulo applies to recordings shorter than one
+    window too, exactly as in the reference (300 samples -> 240, which then has no frame at all)."""
+    spare = (len(samples) - spec.WIN) % spec.HOP
+    return samples[:len(samples) - spare] if spare else samples
 
 
 def extend_context(samples):
@@ -138,6 +138,8 @@ def handle_signals(mixedpath, noisepospath, noisenegpath):
         noisepossamples = _read_context(noisepospath)
         noisenegsamples = _read_context(noisenegpath)
         mixedsamples = trim_to_frames(normalise(mixedsamples))
+        if len(mixedsamples) < spec.WIN:
+            raise ValueError("%s: shorter than one %d-sample STFT window" % (mixedpath, spec.WIN))
         return normalise(noisepossamples), normalise(noisenegsamples), mixedsamples
     except Exception:
         print('error in threads')
@@ -163,7 +165,7 @@ def _load_weights(kind):
 def get_engine(kind):
     if kind not in _engines:
         from . import engine
-        _engines[kind] = engine.Engine(kind, _load_weights(kind))
+        _engines[kind] = engine.Engine(kind, _load_weights(kind), device=_device_index)
     return _engines[kind]
 
 
@@ -184,25 +186,42 @@ def _enhance_files(kind, mixedpath, ctx_a_path, ctx_b_path):
     return res["denoised_wav"][0], res["mixed_wav"][0]
 
 
-def apply_snc(mixedpath, pospath, negpath, save_to):
-    """Selective noise suppression: keep `pos`-like noise, remove `neg`-like noise
-    (SN/apply.py:339-472).  Writes save_to plus the *mixed_processed / *removed / *compensated
-    side files named by the reference's save_to[:-12] rule."""
-    denoised_samples, mixed_samples = _enhance_files(spec.DENOISER, mixedpath, pospath, negpath)
+def side_prefix(save_to):
+    """Prefix of the side files written next to `save_to`.  The reference cuts 12 characters off the
+    output path (`save_to[:-12]`, SN/apply.py:457-470) -- right for its default `.../denoised.wav`
+    and for any `<prefix>denoised.wav`, wrong for everything else (for `out/a.wav` the cut eats the
+    directory, and in directory mode every clip would overwrite the same three files).  So: the
+    reference's cut when the name ends in `denoised.wav`, else `<output without .wav>_`."""
+    if os.path.basename(save_to).endswith('denoised.wav'):
+        return save_to[:-12]
+    return os.path.splitext(save_to)[0] + '_'
+
+
+def write_snc_outputs(save_to, denoised_samples, mixed_samples):
+    """The four files of SN/apply.py:456-472: denoised, mixed_processed (STFT->iSTFT round trip of
+    the input), removed = mixed - denoised, compensated = denoised + removed * factor with the
+    factor FLAGS.compensate or, under --ac, snr_est / 20.  Returns (snr_est, factor)."""
+    pre = side_prefix(save_to)
     wavwrite(save_to, FLAGS.Fs, denoised_samples)
-    wavwrite(save_to[:-12] + 'mixed_processed.wav', FLAGS.Fs, mixed_samples)
+    wavwrite(pre + 'mixed_processed.wav', FLAGS.Fs, mixed_samples)
     removed_samples = mixed_samples - denoised_samples
-    wavwrite(save_to[:-12] + 'removed.wav', FLAGS.Fs, removed_samples)
+    wavwrite(pre + 'removed.wav', FLAGS.Fs, removed_samples)
     with np.errstate(divide="ignore", invalid="ignore"):
         snr_est = np.mean(np.square(denoised_samples)) / np.mean(np.square(removed_samples))
     print(snr_est)
     print('---------------------------')
-    if not FLAGS.ac:
-        compensation_factor = FLAGS.compensate
-    else:
-        compensation_factor = snr_est / 20
-    compensated_samples = denoised_samples + removed_samples * compensation_factor
-    wavwrite(save_to[:-12] + 'compensated.wav', FLAGS.Fs, compensated_samples.astype(np.float32))
+    factor = snr_est / 20 if FLAGS.ac else FLAGS.compensate
+    compensated_samples = denoised_samples + removed_samples * factor
+    wavwrite(pre + 'compensated.wav', FLAGS.Fs, compensated_samples.astype(np.float32))
+    return snr_est, factor
+
+
+def apply_snc(mixedpath, pospath, negpath, save_to):
+    """Selective noise suppression: keep `pos`-like noise, remove `neg`-like noise
+    (SN/apply.py:339-472).  Writes save_to plus the *mixed_processed / *removed / *compensated
+    side files (naming: side_prefix)."""
+    denoised_samples, mixed_samples = _enhance_files(spec.DENOISER, mixedpath, pospath, negpath)
+    write_snc_outputs(save_to, denoised_samples, mixed_samples)
 
 
 def apply_denoiser(mixedpath, negpath, save_to):
@@ -216,8 +235,67 @@ def apply_separator(mixedpath, cleanpath, noisepath, save_to):
     """SS/apply.py:288-397: keep the `cleanpath` (target, --pos) speaker, remove the `noisepath`
     (interferer, --neg) speaker.  resnet_block order is (noise, clean), SS/main.py:205-242."""
     denoised_samples, mixed_samples = _enhance_files(spec.SEPARATOR, mixedpath, noisepath, cleanpath)
+    write_separator_outputs(save_to, denoised_samples, mixed_samples)
+
+
+def write_separator_outputs(save_to, denoised_samples, mixed_samples):
+    """SS/apply.py:391-397: the separated target and the round trip of the input."""
     wavwrite(save_to, FLAGS.Fs, denoised_samples)
-    wavwrite(save_to[:-12] + 'mixed_processed.wav', FLAGS.Fs, mixed_samples)
+    wavwrite(side_prefix(save_to) + 'mixed_processed.wav', FLAGS.Fs, mixed_samples)
+
+
+def apply_batch(kind, jobs):
+    """Directory mode (README.md:59-66) as ONE batch: `jobs` is a list of (mixedpath, pospath,
+    negpath, save_to).  All recordings go through the hot path in a single ragged
+    `nhans_enhance_clips` call; under `python -m torch.distributed.run` (WORLD_SIZE > 1) the clips
+    are sharded over the ranks (clip i -> rank floor(i*G/N), dist.py), each rank runs its block on
+    its own GPU, one all-gather reassembles the waveforms and rank 0 writes the files.  Returns the
+    number of clips written by this rank."""
+    import torch
+    from . import dist as nd
+    sigs, keep = [], []
+    for job in jobs:
+        mixedpath, pospath, negpath, _ = job
+        a_path, b_path = (pospath, negpath) if kind == spec.DENOISER else (negpath, pospath)
+        sig = handle_signals(mixedpath, a_path, b_path)
+        if sig is None:                     # unreadable triple: reported by handle_signals, skipped
+            continue
+        sigs.append(sig)
+        keep.append(job)
+    if not sigs:
+        return 0
+    ca = [s[0] for s in sigs]
+    cb = [s[1] for s in sigs]
+    mixes = [s[2] for s in sigs]
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    eng = get_engine(kind)
+    if world > 1:
+        import torch.distributed as tdist
+        if not tdist.is_initialized():
+            tdist.init_process_group("nccl" if os.environ.get("NHANS_DIST_BACKEND", "nccl") == "nccl" else "gloo")
+        gather_dev = eng.device if tdist.get_backend() == "nccl" else torch.device("cpu")
+
+        def run(m, a, b):
+            if not m:
+                return []
+            res = eng.enhance(m, a, b, want_mixed=True)
+            # denoised and round trip travel in one tensor per clip: ONE data all-gather (SURVEY 8e)
+            return [torch.from_numpy(np.concatenate([d, x])).to(gather_dev)
+                    for d, x in zip(res["denoised_wav"], res["mixed_wav"])]
+        both = nd.enhance_sharded(run, mixes, ca, cb, gather_dev)
+        if rank != 0:
+            return 0
+        outs = [(t[:t.numel() // 2].cpu().numpy(), t[t.numel() // 2:].cpu().numpy()) for t in both]
+    else:
+        res = eng.enhance(mixes, ca, cb, want_mixed=True)
+        outs = list(zip(res["denoised_wav"], res["mixed_wav"]))
+    for (_, _, _, save_to), (den, mixed) in zip(keep, outs):
+        if kind == spec.DENOISER:
+            write_snc_outputs(save_to, den, mixed)
+        else:
+            write_separator_outputs(save_to, den, mixed)
+    return len(outs)
 
 
 # ------------------------------------------------------------------------------ demo / eval mode
@@ -338,18 +416,37 @@ def _pairs(a):
         yield a.input, a.pos, a.neg, a.output
 
 
+def _run_cli(kind, a):
+    jobs = list(_pairs(a))
+    if os.path.isdir(a.input) or int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        _bind_rank_device()
+        apply_batch(kind, jobs)
+    else:
+        for mixed, pos, neg, out in jobs:
+            (apply_snc if kind == spec.DENOISER else apply_separator)(mixed, pos, neg, out)
+
+
+def _bind_rank_device():
+    """One process per GPU under torch.distributed.run: LOCAL_RANK picks the device.  Runs before
+    anything has touched the GPU."""
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if local and all(k not in _engines for k in (spec.DENOISER, spec.SEPARATOR)):
+        import torch
+        torch.cuda.set_device(local)
+        global _device_index
+        _device_index = local
+
+
 def main(argv=None):
-    """`nhans_denoiser` (setup.py:46)."""
-    a = _parse(argv, 'nhans_denoiser')
-    for mixed, pos, neg, out in _pairs(a):
-        apply_snc(mixed, pos, neg, out)
+    """`nhans_denoiser` (setup.py:46).  `--input/--output` (and optionally `--pos/--neg`) may be
+    directories: files are paired by name and processed as one batch; launched through
+    `python -m torch.distributed.run --nproc-per-node N -m ...` the batch is sharded over N GPUs."""
+    _run_cli(spec.DENOISER, _parse(argv, 'nhans_denoiser'))
 
 
 def main_separator(argv=None):
     """`nhans_separator` (setup.py:48)."""
-    a = _parse(argv, 'nhans_separator')
-    for mixed, pos, neg, out in _pairs(a):
-        apply_separator(mixed, pos, neg, out)
+    _run_cli(spec.SEPARATOR, _parse(argv, 'nhans_separator'))
 
 
 if __name__ == '__main__':

@@ -4,6 +4,14 @@
 
 namespace nhans {
 
+// Clamp to the f16 range before a split (hi/lo) store; true if anything was out of range or NaN.
+__device__ __forceinline__ bool split_clamp(float4& v) {
+    const bool sat = !(fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))) < 65504.f);
+    v.x = fminf(fmaxf(v.x, -65504.f), 65504.f); v.y = fminf(fmaxf(v.y, -65504.f), 65504.f);
+    v.z = fminf(fmaxf(v.z, -65504.f), 65504.f); v.w = fminf(fmaxf(v.w, -65504.f), 65504.f);
+    return sat;
+}
+
 // ---------------------------------------------------------------------------------------------
 // First conv of a block whose input is the 1-channel log-magnitude image (K = KH*KW <= 32):
 // main stack resblock1_1_conv1 (4x4, SN/main.py:162-168) and the tower's noise_resblock1_1_conv1
@@ -51,6 +59,7 @@ __global__ void __launch_bounds__(256) direct_conv64(const DirectArgs a) {
             // split NHWC: group g = c/32 of pixel m is one 128-byte line, 32 hi halfs then 32 lo halfs
             typedef _Float16 h4 __attribute__((ext_vector_type(4)));
             h4 hi, lo;
+            if (split_clamp(acc) && a.sat) atomicOr(a.sat, kSatActivation);
             hi.x = (_Float16)acc.x; hi.y = (_Float16)acc.y; hi.z = (_Float16)acc.z; hi.w = (_Float16)acc.w;
             lo.x = (_Float16)(acc.x - (float)hi.x); lo.y = (_Float16)(acc.y - (float)hi.y);
             lo.z = (_Float16)(acc.z - (float)hi.z); lo.w = (_Float16)(acc.w - (float)hi.w);
@@ -119,6 +128,7 @@ __global__ void __launch_bounds__(256) direct_conv64_4x4(const DirectArgs a, int
             if constexpr (SPLIT) {
                 typedef _Float16 h4 __attribute__((ext_vector_type(4)));
                 h4 hi, lo;
+                if (split_clamp(acc) && a.sat) atomicOr(a.sat, kSatActivation);
                 hi.x = (_Float16)acc.x; hi.y = (_Float16)acc.y; hi.z = (_Float16)acc.z; hi.w = (_Float16)acc.w;
                 lo.x = (_Float16)(acc.x - (float)hi.x); lo.y = (_Float16)(acc.y - (float)hi.y);
                 lo.z = (_Float16)(acc.z - (float)hi.z); lo.w = (_Float16)(acc.w - (float)hi.w);
@@ -146,7 +156,7 @@ void launch_unsplit(const float* src, int64_t M, int C, float* dst, hipStream_t 
     if (total <= 0) return;
     int64_t blocks = (total + 255) / 256;
     if (blocks > 256 * 32) blocks = 256 * 32;
-    hipLaunchKernelGGL(unsplit_kernel, dim3((unsigned)blocks), dim3(256), 0, s, src, total, C, dst);
+    NHANS_LAUNCH("unsplit", unsplit_kernel, dim3((unsigned)blocks), dim3(256), 0, s, src, total, C, dst);
 }
 
 void launch_direct_conv64(const DirectArgs& a, hipStream_t s) {
@@ -154,13 +164,13 @@ void launch_direct_conv64(const DirectArgs& a, hipStream_t s) {
         const int tiles_r = (a.Ho + 3) / 4, tiles_c = (a.Wo + 15) / 16;
         const int ntiles = (a.M / (a.Ho * a.Wo)) * tiles_r * tiles_c;
         const int grid4 = ntiles < 256 * 8 ? ntiles : 256 * 8;
-        if (a.out_split) hipLaunchKernelGGL(direct_conv64_4x4<1>, dim3(grid4), dim3(256), 0, s, a, tiles_r, tiles_c, ntiles);
-        else hipLaunchKernelGGL(direct_conv64_4x4<0>, dim3(grid4), dim3(256), 0, s, a, tiles_r, tiles_c, ntiles);
+        if (a.out_split) NHANS_LAUNCH("direct_conv64_4x4", direct_conv64_4x4<1>, dim3(grid4), dim3(256), 0, s, a, tiles_r, tiles_c, ntiles);
+        else NHANS_LAUNCH("direct_conv64_4x4", direct_conv64_4x4<0>, dim3(grid4), dim3(256), 0, s, a, tiles_r, tiles_c, ntiles);
         return;
     }
     int grid = (a.M + 15) / 16;
     if (grid > 256 * 16) grid = 256 * 16;
-    hipLaunchKernelGGL(direct_conv64, dim3(grid), dim3(256), 0, s, a);
+    NHANS_LAUNCH("direct_conv64", direct_conv64, dim3(grid), dim3(256), 0, s, a);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -181,7 +191,7 @@ __global__ void frame_index_kernel(const int64_t* off, int nclips, int64_t total
 void launch_frame_index(const int64_t* frame_offsets_dev, int nclips, int64_t total, int* f_clip, int* f_t,
                         int* f_T, hipStream_t s) {
     if (total <= 0) return;
-    hipLaunchKernelGGL(frame_index_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s,
+    NHANS_LAUNCH("frame_index", frame_index_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s,
                        frame_offsets_dev, nclips, total, f_clip, f_t, f_T);
 }
 
@@ -206,7 +216,7 @@ void launch_gather_windows(const float* logmag, const int* f_t, const int* f_T, 
     if (n <= 0) return;
     int64_t blocks = ((int64_t)n * kMixWin * kBins + 255) / 256;
     if (blocks > 256 * 32) blocks = 256 * 32;
-    hipLaunchKernelGGL(gather_windows_kernel, dim3((unsigned)blocks), dim3(256), 0, s, logmag, f_t, f_T, g0, n, xw);
+    NHANS_LAUNCH("gather_windows", gather_windows_kernel, dim3((unsigned)blocks), dim3(256), 0, s, logmag, f_t, f_T, g0, n, xw);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -234,7 +244,7 @@ __global__ void __launch_bounds__(256) avgpool_kernel(const float* x, int HW, in
 
 void launch_avgpool(const float* x, int B, int HW, int C, int split, float* out, hipStream_t s) {
     if (B <= 0) return;
-    hipLaunchKernelGGL(avgpool_kernel, dim3(B, C / 64), dim3(256), 0, s, x, HW, C, split, out);
+    NHANS_LAUNCH("avgpool", avgpool_kernel, dim3(B, C / 64), dim3(256), 0, s, x, HW, C, split, out);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -275,7 +285,7 @@ __global__ void __launch_bounds__(256) cond_kernel(const float* ea, const float*
 void launch_cond(const float* ea, const float* eb, int nclips, const float* Wc, const float* base, int ncols,
                  float* cb, hipStream_t s) {
     if (nclips <= 0) return;
-    hipLaunchKernelGGL(cond_kernel, dim3(nclips, (ncols + 63) / 64), dim3(256), 0, s, ea, eb, Wc, base, ncols, cb);
+    NHANS_LAUNCH("cond_proj", cond_kernel, dim3(nclips, (ncols + 63) / 64), dim3(256), 0, s, ea, eb, Wc, base, ncols, cb);
 }
 
 }  // namespace nhans

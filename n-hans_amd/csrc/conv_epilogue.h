@@ -67,6 +67,7 @@ __device__ __forceinline__ void conv_epilogue_sweep(const ConvArgs& a, const flo
     if constexpr (IDM != 0) idwv = *reinterpret_cast<const f32x4*>(a.idw + n);
     const int hoff = (n >> 5) * 64 + (n & 31);                // half index inside a split-NHWC pixel
     const float lo_clamp = a.relu ? 0.f : -3.0e38f;           // branch-free ReLU
+    bool sat = false;                                         // split output: a value that does not fit f16
 #pragma unroll 1
     for (int pg = 0; pg < PASSES; pg += GP) {
         f32x4 yv[GP];
@@ -102,6 +103,8 @@ __device__ __forceinline__ void conv_epilogue_sweep(const ConvArgs& a, const flo
                 if constexpr (OUTS) {
                     f16x4 h, l;
                     float yc;
+                    // (negated comparison: NaN counts as saturated too)
+                    sat |= !(fmaxf(fmaxf(fabsf(y.x), fabsf(y.y)), fmaxf(fabsf(y.z), fabsf(y.w))) < 65504.f);
                     yc = fminf(fmaxf(y.x, -65504.f), 65504.f); h.x = (_Float16)yc; l.x = (_Float16)(yc - (float)h.x);
                     yc = fminf(fmaxf(y.y, -65504.f), 65504.f); h.y = (_Float16)yc; l.y = (_Float16)(yc - (float)h.y);
                     yc = fminf(fmaxf(y.z, -65504.f), 65504.f); h.z = (_Float16)yc; l.z = (_Float16)(yc - (float)h.z);
@@ -114,6 +117,10 @@ __device__ __forceinline__ void conv_epilogue_sweep(const ConvArgs& a, const flo
                 }
             }
         }
+    }
+    if constexpr (OUTS) {
+        // the split layout clamps to +-65504: tell the host (nhans_take_status) instead of going on silently
+        if (sat && a.sat) atomicOr(a.sat, kSatActivation);
     }
 }
 

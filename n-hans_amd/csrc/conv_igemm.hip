@@ -326,15 +326,11 @@ __global__ void __launch_bounds__(256) conv_igemm(const ConvArgs a) {
 template <int BN, int WM, int WN, int PREC, int ABL = 0>
 static void launch_t(const ConvArgs& a, hipStream_t s) {
     constexpr size_t lds = (2 * BM * LDA + 2 * BK * BN) * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm<BN, WM, WN, PREC, ABL>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
-    }
+    static unsigned long long attr_devices = 0;
+    set_max_dynamic_lds(reinterpret_cast<const void*>(&conv_igemm<BN, WM, WN, PREC, ABL>), lds, &attr_devices, "conv_igemm");
     const int mtiles = (a.M + BM - 1) / BM;
     const int grid = mtiles * (a.N / BN);
-    hipLaunchKernelGGL((conv_igemm<BN, WM, WN, PREC, ABL>), dim3(grid), dim3(256), lds, s, a);
+    NHANS_LAUNCH("conv_igemm", (conv_igemm<BN, WM, WN, PREC, ABL>), dim3(grid), dim3(256), lds, s, a);
 }
 
 double launch_conv_igemm(const ConvArgs& a, hipStream_t s) {
@@ -350,9 +346,9 @@ double launch_conv_igemm(const ConvArgs& a, hipStream_t s) {
         return 2.0 * (double)a.M * k * (double)a.Nreal;
     }
     if (a.prec == 1) {
-        static const int abl = [] { const char* e = getenv("NHANS_ABLATE"); return e ? atoi(e) : 0; }();
         if (a.N % 128 == 0) {
-            switch (abl) {      // timing experiments only: results are wrong for abl != 0
+#ifdef NHANS_DEV
+            switch (dev_ablate()) {      // timing experiments only: results are wrong for a non-zero value
                 case 1: launch_t<128, 2, 2, 1, 1>(a, s); break;
                 case 14: launch_t<128, 2, 2, 1, 14>(a, s); break;
                 case 16: launch_t<128, 2, 2, 1, 16>(a, s); break;
@@ -362,6 +358,9 @@ double launch_conv_igemm(const ConvArgs& a, hipStream_t s) {
                 case 62: launch_t<128, 2, 2, 1, 62>(a, s); break;
                 default: launch_t<128, 2, 2, 1>(a, s);
             }
+#else
+            launch_t<128, 2, 2, 1>(a, s);
+#endif
         } else launch_t<64, 4, 1, 1>(a, s);
     } else {
         if (a.N % 128 == 0) launch_t<128, 2, 2, 0>(a, s); else launch_t<64, 4, 1, 0>(a, s);

@@ -52,7 +52,7 @@ __global__ void __launch_bounds__(512) conv_igemm_dma(const ConvArgs a) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
-    const long long t_start = a.dbg ? (long long)__builtin_amdgcn_s_memtime() : 0;
+    const long long t_start = (kDev && a.dbg) ? (long long)__builtin_amdgcn_s_memtime() : 0;
 
     // XCD-aware, bijective remap of the linear workgroup id
     const int ntn = a.N / BN;
@@ -268,7 +268,7 @@ __global__ void __launch_bounds__(512) conv_igemm_dma(const ConvArgs a) {
         wait_vmcnt<0>();
     }
     __builtin_amdgcn_s_barrier();
-    if (a.dbg) t_loop = (long long)__builtin_amdgcn_s_memtime();
+    if (kDev && a.dbg) t_loop = (long long)__builtin_amdgcn_s_memtime();
 
     if constexpr (PINGPONG) {
         // Ping-pong: waves w and w+4 share a SIMD.  Each iteration has two phases separated by
@@ -309,14 +309,14 @@ __global__ void __launch_bounds__(512) conv_igemm_dma(const ConvArgs a) {
         int st = 0;                                    // ring stage of chunk `it`
         long long ph0 = 0, ph1 = 0, ph2 = 0, ph3 = 0, tq = 0;          // dev tool: in-loop phase cycles
         for (int it = 0; it < total; ++it) {
-            if (a.dbg) tq = (long long)__builtin_amdgcn_s_memtime();
+            if (kDev && a.dbg) tq = (long long)__builtin_amdgcn_s_memtime();
             if (it + 2 < total) {
                 const int st2 = st >= 1 ? st - 1 : st + 2;             // (st + 2) % 3
                 NH_ISSUE(st2)                                           // chunk it+2 -> stage freed at it-1
             }
-            if (a.dbg) { __builtin_amdgcn_sched_barrier(0); const long long t = (long long)__builtin_amdgcn_s_memtime(); ph0 += t - tq; tq = t; }
+            if (kDev && a.dbg) { __builtin_amdgcn_sched_barrier(0); const long long t = (long long)__builtin_amdgcn_s_memtime(); ph0 += t - tq; tq = t; }
             NH_READ_FRAGS(st)
-            if (a.dbg) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_sched_barrier(0); const long long t = (long long)__builtin_amdgcn_s_memtime(); ph1 += t - tq; tq = t; }
+            if (kDev && a.dbg) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_sched_barrier(0); const long long t = (long long)__builtin_amdgcn_s_memtime(); ph1 += t - tq; tq = t; }
             NH_MFMA_FRAGS()
             if constexpr (GRP) {
                 if (ksplit == 1 && --gleft == 0) {      // close the group: tot += acc, acc = 0
@@ -332,14 +332,14 @@ __global__ void __launch_bounds__(512) conv_igemm_dma(const ConvArgs a) {
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
-            if (a.dbg) { const long long t = (long long)__builtin_amdgcn_s_memtime(); ph2 += t - tq; tq = t; }
+            if (kDev && a.dbg) { const long long t = (long long)__builtin_amdgcn_s_memtime(); ph2 += t - tq; tq = t; }
             // chunk it+1 must have landed (in every wave) before anyone reads it; chunk it+2 stays in flight
             if (it + 2 < total) wait_vmcnt<G>(); else wait_vmcnt<0>();
             __builtin_amdgcn_s_barrier();
-            if (a.dbg) { const long long t = (long long)__builtin_amdgcn_s_memtime(); ph3 += t - tq; }
+            if (kDev && a.dbg) { const long long t = (long long)__builtin_amdgcn_s_memtime(); ph3 += t - tq; }
             st = st == 2 ? 0 : st + 1;
         }
-        if (a.dbg && tid == 0) {
+        if (kDev && a.dbg && tid == 0) {
             long long* d = a.dbg + (size_t)(4 << 20) + (size_t)blockIdx.x * 4;
             d[0] = ph0; d[1] = ph1; d[2] = ph2; d[3] = ph3;
         }
@@ -355,7 +355,7 @@ __global__ void __launch_bounds__(512) conv_igemm_dma(const ConvArgs a) {
 #undef NH_READ_FRAGS
 #undef NH_MFMA_FRAGS
 
-    if (a.dbg) t_epi = (long long)__builtin_amdgcn_s_memtime();
+    if (kDev && a.dbg) t_epi = (long long)__builtin_amdgcn_s_memtime();
     if constexpr (GRP) {
         if (ksplit == 1) {                              // last (partial) group, then the sum is the result
 #pragma unroll
@@ -430,7 +430,7 @@ __global__ void __launch_bounds__(512) conv_igemm_dma(const ConvArgs a) {
         static_assert(conv_epilogue_lds_bytes<DBM, BN>() <= (size_t)DSTAGES * STAGE * sizeof(float), "epilogue LDS");
         conv_epilogue<TM, TN, PREC, 512, DBM, BN>(a, acc, smem, EpiTile{m0, 0, 0, 0, 0, 0}, wm * 64, wn * TN * 32, nt * BN, tid, lane);
     }
-    if (a.dbg) {                                       // dev tool (tools/conv_phase_cycles.py)
+    if (kDev && a.dbg) {                                       // dev tool (tools/conv_phase_cycles.py)
         __syncthreads();
         if (tid == 0) {
             long long* d = a.dbg + (size_t)blockIdx.x * 4;
@@ -442,13 +442,9 @@ __global__ void __launch_bounds__(512) conv_igemm_dma(const ConvArgs a) {
 template <int BN, int PREC, int ABL = 0, int PINGPONG = 0, int GRP = 0>
 static void launch_dma_g(const ConvArgs& a, int grid, int ks, hipStream_t s) {
     constexpr size_t lds = (size_t)DSTAGES * (DBM * 32 + DBK * BN) * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_dma<BN, PREC, ABL, PINGPONG, GRP>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
-    }
-    hipLaunchKernelGGL((conv_igemm_dma<BN, PREC, ABL, PINGPONG, GRP>), dim3(grid, ks), dim3(512), lds, s, a);
+    static unsigned long long attr_devices = 0;
+    set_max_dynamic_lds(reinterpret_cast<const void*>(&conv_igemm_dma<BN, PREC, ABL, PINGPONG, GRP>), lds, &attr_devices, "conv_igemm_dma");
+    NHANS_LAUNCH("conv_igemm_dma", (conv_igemm_dma<BN, PREC, ABL, PINGPONG, GRP>), dim3(grid, ks), dim3(512), lds, s, a);
 }
 
 template <int BN, int PREC, int ABL = 0, int PINGPONG = 0>
@@ -479,7 +475,8 @@ static void launch_dma_t(const ConvArgs& a0, hipStream_t s) {
 
 void launch_conv_igemm_dma(const ConvArgs& a, hipStream_t s) {
     if (a.prec == 1) {
-        static const int abl = [] { const char* e = getenv("NHANS_ABLATE"); return e ? atoi(e) : 0; }();
+#ifdef NHANS_DEV
+        const int abl = dev_ablate();
         if (a.N % 128 == 0) {
             switch (abl) {          // timing experiments only: results are wrong for abl != 0
                 case 1: launch_dma_t<128, 1, 1>(a, s); break;
@@ -493,6 +490,9 @@ void launch_conv_igemm_dma(const ConvArgs& a, hipStream_t s) {
             }
         } else if (abl == 16) launch_dma_t<64, 1, 0, 1>(a, s);
         else launch_dma_t<64, 1>(a, s);
+#else
+        if (a.N % 128 == 0) launch_dma_t<128, 1>(a, s); else launch_dma_t<64, 1>(a, s);
+#endif
     } else {
         if (a.N % 128 == 0) launch_dma_t<128, 0>(a, s); else launch_dma_t<64, 0>(a, s);
     }

@@ -383,15 +383,11 @@ __global__ void __launch_bounds__((NCW + NPW) * 64) conv_igemm_halo(const ConvAr
 
 template <int BN, int PREC, int DBG = 0, int ABL = 0> static void launch_halo_t(const ConvArgs& a, hipStream_t s) {
     constexpr size_t lds = (size_t)(2 * HR * 32 + BST * 32 * BN) * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_halo<BN, PREC, DBG, ABL>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
-    }
+    static unsigned long long attr_devices = 0;
+    set_max_dynamic_lds(reinterpret_cast<const void*>(&conv_igemm_halo<BN, PREC, DBG, ABL>), lds, &attr_devices, "conv_igemm_halo");
     const int mtiles = (a.M + HBM - 1) / HBM;
     const int grid = mtiles * (a.N / BN);
-    hipLaunchKernelGGL((conv_igemm_halo<BN, PREC, DBG, ABL>), dim3(grid), dim3((NCW + NPW) * 64), lds, s, a);
+    NHANS_LAUNCH("conv_igemm_halo", (conv_igemm_halo<BN, PREC, DBG, ABL>), dim3(grid), dim3((NCW + NPW) * 64), lds, s, a);
 }
 
 bool conv_igemm_halo_eligible(const ConvArgs& a) {
@@ -415,7 +411,8 @@ void launch_conv_igemm_halo(const ConvArgs& a0, hipStream_t s) {
     ConvArgs a = a0;
     a.fdWP = make_fastdiv((uint32_t)(a.Wo + a.seg[0].KW - 1));
     const bool wide = a.N % 128 == 0;
-    static const int abl = [] { const char* e = getenv("NHANS_ABLATE"); return e ? atoi(e) : 0; }();
+#ifdef NHANS_DEV
+    const int abl = dev_ablate();
     if (a.prec == 1 && a.dbg) {     // cycle stamps, optionally of an ablated loop
 #define NH_DBG_CASE(V) case V: if (wide) launch_halo_t<128, 1, 1, V>(a, s); else launch_halo_t<64, 1, 1, V>(a, s); break;
         switch (abl) {
@@ -434,6 +431,10 @@ void launch_conv_igemm_halo(const ConvArgs& a0, hipStream_t s) {
     } else {
         if (wide) launch_halo_t<128, 0>(a, s); else launch_halo_t<64, 0>(a, s);
     }
+#else
+    if (a.prec == 1) { if (wide) launch_halo_t<128, 1>(a, s); else launch_halo_t<64, 1>(a, s); }
+    else { if (wide) launch_halo_t<128, 0>(a, s); else launch_halo_t<64, 0>(a, s); }
+#endif
 }
 
 }  // namespace nhans

@@ -293,19 +293,15 @@ bool plan_tiles(int Ho, int Wo, int KH, int KW, int rows, int* th_, int* tw_, do
 
 template <int BN, int PREC, int ABL = 0> void launch_t2(const ConvArgs& a, int images, hipStream_t s) {
     constexpr size_t lds = (size_t)(2 * kHR2 * 32 + T2_BST * 32 * BN) * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_halo2d<BN, PREC, kHR2, ABL>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
-    }
+    static unsigned long long attr_devices = 0;
+    set_max_dynamic_lds(reinterpret_cast<const void*>(&conv_igemm_halo2d<BN, PREC, kHR2, ABL>), lds, &attr_devices, "conv_igemm_halo2d");
     const int grid = images * a.t2_ntr * a.t2_ntc * (a.N / BN);
-    hipLaunchKernelGGL((conv_igemm_halo2d<BN, PREC, kHR2, ABL>), dim3(grid), dim3((T2_NCW + T2_NPW) * 64), lds, s, a);
+    NHANS_LAUNCH("conv_igemm_halo2d", (conv_igemm_halo2d<BN, PREC, kHR2, ABL>), dim3(grid), dim3((T2_NCW + T2_NPW) * 64), lds, s, a);
 }
 }  // namespace
 
 bool launch_conv_igemm_halo2d(const ConvArgs& a0, hipStream_t s) {
-    static const bool enabled = [] { const char* e = getenv("NHANS_HALO2D"); return !(e && atoi(e) == 0); }();
+    const bool enabled = dev_halo2d_enabled();
     const ConvSeg& g = a0.seg[0];
     if (!enabled || a0.nseg != 1 || a0.N % 64 != 0 || a0.N % 128 == 0) return false;
     if (g.sh != 1 || g.sw != 1 || a0.Ho != g.H || a0.Wo != g.W || g.KW < 2 || g.KH * g.KW < 3) return false;
@@ -318,10 +314,12 @@ bool launch_conv_igemm_halo2d(const ConvArgs& a0, hipStream_t s) {
     ConvArgs a = a0;
     a.t2_th = th; a.t2_tw = tw;
     a.t2_ntr = (a.Ho + th - 1) / th; a.t2_ntc = (a.Wo + tw - 1) / tw;
-    static const int abl = [] { const char* e = getenv("NHANS_ABLATE"); return e ? atoi(e) : 0; }();
-    if (a.prec == 1 && abl == 512) launch_t2<64, 1, 1>(a, images, s);     // timing experiment: no per-tap barrier
-    else if (a.prec == 1 && abl == 1024) launch_t2<64, 1, 2>(a, images, s);   // reads interleaved 1:1 with the MFMAs
-    else if (a.prec == 1) launch_t2<64, 1>(a, images, s);
+#ifdef NHANS_DEV
+    const int abl = dev_ablate();
+    if (a.prec == 1 && abl == 512) { launch_t2<64, 1, 1>(a, images, s); return true; }     // timing experiment: no per-tap barrier
+    if (a.prec == 1 && abl == 1024) { launch_t2<64, 1, 2>(a, images, s); return true; }   // reads interleaved 1:1 with the MFMAs
+#endif
+    if (a.prec == 1) launch_t2<64, 1>(a, images, s);
     else launch_t2<64, 0>(a, images, s);
     return true;
 }

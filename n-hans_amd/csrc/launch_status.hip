@@ -1,0 +1,56 @@
+// Launch-error channel of libnhans_hip.so (declared in nhans_kernels.h): the launchers are plain
+// void functions deep inside the launch sequences; instead of threading a status through every one
+// of them, each records the outcome of its launch here and the C-ABI entry point collects it.
+#include "nhans_kernels.h"
+
+#include <atomic>
+#include <cstdlib>
+
+namespace nhans {
+
+namespace {
+thread_local hipError_t g_first_err = hipSuccess;
+thread_local const char* g_first_where = "";
+
+void keep(hipError_t e, const char* where) {
+    if (e != hipSuccess && g_first_err == hipSuccess) {
+        g_first_err = e;
+        g_first_where = where;
+    }
+}
+}  // namespace
+
+void note_launch(const char* kernel) { keep(hipGetLastError(), kernel); }
+
+void set_max_dynamic_lds(const void* fn, size_t bytes, unsigned long long* done_mask, const char* kernel) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) { keep(e, kernel); return; }
+    auto* mask = reinterpret_cast<std::atomic<unsigned long long>*>(done_mask);
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (dev < 64 && (mask->load(std::memory_order_acquire) & bit)) return;
+    e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e != hipSuccess) { (void)hipGetLastError(); keep(e, kernel); return; }
+    if (dev < 64) mask->fetch_or(bit, std::memory_order_release);
+}
+
+hipError_t take_launch_error(const char** kernel) {
+    const hipError_t e = g_first_err;
+    if (kernel) *kernel = g_first_where;
+    g_first_err = hipSuccess;
+    g_first_where = "";
+    return e;
+}
+
+#ifdef NHANS_DEV
+int dev_ablate() {
+    static const int v = [] { const char* e = getenv("NHANS_ABLATE"); return e ? atoi(e) : 0; }();
+    return v;
+}
+bool dev_halo2d_enabled() {
+    static const bool v = [] { const char* e = getenv("NHANS_HALO2D"); return !(e && atoi(e) == 0); }();
+    return v;
+}
+#endif
+
+}  // namespace nhans

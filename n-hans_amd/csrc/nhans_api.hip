@@ -117,7 +117,12 @@ struct nhans_ctx {
     int conv_variant = -1;  // 0: 128-pixel register-staged conv kernel, 1: 256-pixel LDS-DMA kernel,
                             // 2: halo-reuse / wave-specialised LDS-DMA kernel where the conv allows it, else 1;
                             // -1: automatic (measured best: 2 for split-f16, register-staged for f32)
-    long long* dbg = nullptr;   // dev tool: per-workgroup cycle stamps of the last conv launch
+    long long* dbg = nullptr;   // NHANS_DEV builds: per-workgroup cycle stamps of the last conv launch
+    int* status_dev = nullptr;  // sticky NHANS_STATUS_* bits set by kernels (nhans_take_status)
+    // ordering of consecutive calls that share the workspace (see include/nhans_hip.h)
+    hipEvent_t tail_ev = nullptr;
+    hipStream_t last_stream = nullptr;
+    bool have_tail = false;
 
     const float* A(const std::string& n) const {
         auto it = arr.find(n);
@@ -179,11 +184,17 @@ struct Prof {
     hipStream_t s;
     ProfEntry* e = nullptr;
     hipEvent_t a{}, b{};
+    static hipEvent_t take(nhans_ctx* c) {
+        hipEvent_t ev = nullptr;
+        if (!c->event_pool.empty()) { ev = c->event_pool.back(); c->event_pool.pop_back(); }
+        else (void)hipEventCreate(&ev);
+        return ev;
+    }
     Prof(nhans_ctx* c_, hipStream_t s_, const char* name) : c(c_), s(s_) {
         if (!c->profile) return;
         e = &c->prof[name];
-        (void)hipEventCreate(&a);
-        (void)hipEventCreate(&b);
+        a = take(c);
+        b = take(c);
         (void)hipEventRecord(a, s);
     }
     void done(double flops, double bytes) {
@@ -198,12 +209,13 @@ struct Prof {
 
 void fill_epilogue_defaults(nhans_ctx* c, ConvArgs& a) {
     a.zero = c->A("zero");
+    a.sat = c->status_dev;
     a.img_clip = nullptr; a.tf = nullptr; a.id_mode = 0; a.id = nullptr; a.id_ld = 0;
     a.idw = nullptr; a.idH = a.idW = 0; a.idsh = a.idsw = 1; a.relu = 1; a.aux = nullptr; a.aux_ld = 0;
     a.cb_stride = 0;
     a.prec = c->prec; a.out_split = c->prec; a.id_split = 0; a.ws = nullptr;
     a.variant = c->conv_variant >= 0 ? c->conv_variant : (c->prec == 1 ? 2 : 0);
-    a.dbg = c->dbg;
+    a.dbg = kDev ? c->dbg : nullptr;
     a.kscratch = c->kscratch; a.kscratch_bytes = c->kscratch_bytes; a.kcounter = c->kcounter; a.kcounter_n = c->kcounter_n; a.kgroup = 0;
 }
 
@@ -249,7 +261,7 @@ int embed_impl(nhans_ctx* c, const float* ctx_lm, int n, float* emb_out, float* 
                 d.Ho = g.hout; d.Wo = g.wout; d.M = nc * g.hout * g.wout; d.out = a1;
                 d.cb = c->A(p + ".c1.cb"); d.cb_stride = 0; d.img_clip = nullptr; d.tf = nullptr;
                 d.relu = 1; d.fdHoWo = make_fastdiv(g.hout * g.wout); d.fdWo = make_fastdiv(g.wout);
-                d.out_split = c->prec;
+                d.out_split = c->prec; d.sat = c->status_dev;
                 Prof pr(c, s, "direct_conv64");
                 launch_direct_conv64(d, s);
                 pr.done(2.0 * d.M * g.kh * g.kw * 64, 0);
@@ -344,7 +356,7 @@ float* run_stack_chunk(nhans_ctx* c, const float* logmag, const StackBufs& sb, i
             int o; same_pad(g.hin, g.kh, 1, &o, &d.pt); same_pad(g.win, g.kw, 1, &o, &d.pl);
             d.Ho = g.hout; d.Wo = g.wout; d.M = n * g.hout * g.wout; d.out = a1;
             d.cb = cb1; d.cb_stride = c->cond_cols; d.img_clip = clipmap;
-            d.tf = c->A(p + ".c1.tf"); d.relu = 1; d.out_split = c->prec;
+            d.tf = c->A(p + ".c1.tf"); d.relu = 1; d.out_split = c->prec; d.sat = c->status_dev;
             d.fdHoWo = make_fastdiv(g.hout * g.wout); d.fdWo = make_fastdiv(g.wout);
             Prof pr(c, s, "direct_conv64");
             launch_direct_conv64(d, s);
@@ -512,6 +524,43 @@ int check_ctx(nhans_ctx* c) {
     return NHANS_OK;
 }
 
+// A launch the runtime rejected anywhere in the sequence just issued -> NHANS_EHIP.
+int launch_status() {
+    const char* where = "";
+    const hipError_t e = take_launch_error(&where);
+    if (e == hipSuccess) return NHANS_OK;
+    return fail(NHANS_EHIP, std::string("kernel launch failed: ") + where + ": " + hipGetErrorString(e));
+}
+
+// Bracket of one hot-path entry point: selects the device, orders the call behind the previous
+// call on this context when that one ran on another stream (they share workspace, pinned tables
+// and split-K tickets), and on the way out collects launch failures and marks the new tail.
+struct Call {
+    nhans_ctx* c;
+    hipStream_t s;
+    int rc;
+    Call(nhans_ctx* c_, void* stream) : c(c_), s(static_cast<hipStream_t>(stream)), rc(check_ctx(c_)) {
+        if (rc) return;
+        (void)take_launch_error(nullptr);               // (a stale record of another context's failure)
+        if (c->have_tail && c->last_stream != s) {
+            const hipError_t e = hipStreamWaitEvent(s, c->tail_ev, 0);
+            if (e != hipSuccess) rc = fail(NHANS_EHIP, std::string("hipStreamWaitEvent: ") + hipGetErrorString(e));
+        }
+    }
+    int finish(int body_rc) {
+        const int lrc = launch_status();
+        if (hipEventRecord(c->tail_ev, s) == hipSuccess) { c->have_tail = true; c->last_stream = s; }
+        return body_rc ? body_rc : lrc;
+    }
+};
+
+__global__ void launch_probe_kernel(int* out) {
+    extern __shared__ int probe_lds[];
+    probe_lds[threadIdx.x] = threadIdx.x;
+    __syncthreads();
+    if (out && threadIdx.x == 0) *out = probe_lds[63];
+}
+
 }  // namespace
 
 // ================================================================================================
@@ -548,6 +597,10 @@ int nhans_create(int model_kind, const void* blob, size_t nbytes, int device_id,
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&c->kcounter), c->kcounter_n * sizeof(int));
     if (e == hipSuccess) e = hipMemset(c->kcounter, 0, c->kcounter_n * sizeof(int));
     if (e != hipSuccess) { nhans_destroy(c); return fail(NHANS_ENOMEM, "split-K scratch allocation failed"); }
+    e = hipMalloc(reinterpret_cast<void**>(&c->status_dev), sizeof(int));
+    if (e == hipSuccess) e = hipMemset(c->status_dev, 0, sizeof(int));
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->tail_ev, hipEventDisableTiming);
+    if (e != hipSuccess) { nhans_destroy(c); return fail(NHANS_EHIP, "status word / ordering event creation failed"); }
     const BlobEntry* ent = reinterpret_cast<const BlobEntry*>(static_cast<const char*>(blob) + sizeof(BlobHeader));
     for (uint32_t i = 0; i < h->n_entries; ++i) {
         if (ent[i].offset % 16 || ent[i].offset + ent[i].nfloats * 4 > nbytes) {
@@ -608,6 +661,9 @@ void nhans_destroy(nhans_ctx* c) {
     (void)hipDeviceSynchronize();
     for (auto& kv : c->prof)
         for (auto& ev : kv.second.pending) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
+    for (hipEvent_t ev : c->event_pool) (void)hipEventDestroy(ev);
+    if (c->tail_ev) (void)hipEventDestroy(c->tail_ev);
+    if (c->status_dev) (void)hipFree(c->status_dev);
     if (c->ws) (void)hipFree(c->ws);
     if (c->kscratch) (void)hipFree(c->kscratch);
     if (c->kcounter) (void)hipFree(c->kcounter);
@@ -622,7 +678,10 @@ int nhans_set_option(nhans_ctx* c, const char* key, int64_t value) {
     if (k == "frames_per_chunk") { if (value < 1) return fail(NHANS_EINVAL, "frames_per_chunk < 1"); c->frames_per_chunk = value; }
     else if (k == "contexts_per_chunk") { if (value < 1) return fail(NHANS_EINVAL, "contexts_per_chunk < 1"); c->contexts_per_chunk = (int)value; }
     else if (k == "profile") c->profile = value != 0;
-    else if (k == "debug_cycles_ptr") c->dbg = reinterpret_cast<long long*>(static_cast<intptr_t>(value));
+    else if (k == "debug_cycles_ptr") {
+        if (!kDev) return fail(NHANS_EINVAL, "debug_cycles_ptr exists only in a NHANS_DEV build (make DEV=1)");
+        c->dbg = reinterpret_cast<long long*>(static_cast<intptr_t>(value));
+    }
     else if (k == "conv_variant") {
         if (value < -1 || value > 2) return fail(NHANS_EINVAL, "conv_variant must be -1 (auto), 0, 1 or 2");
         c->conv_variant = (int)value;
@@ -648,9 +707,9 @@ size_t nhans_workspace_bytes(nhans_ctx* c, int64_t total_frames, int nclips) {
     return b;
 }
 
-int nhans_stft_features(nhans_ctx* c, const float* wav, const int64_t* soff, int nclips, int maxf,
+static int stft_features_body(nhans_ctx* c, const float* wav, const int64_t* soff, int nclips, int maxf,
                         float* logmag, float* phase, void* stream) {
-    int rc = check_ctx(c); if (rc) return rc;
+    int rc = NHANS_OK;
     if (!wav || !soff || !logmag || nclips < 0) return fail(NHANS_EINVAL, "null argument");
     hipStream_t s = static_cast<hipStream_t>(stream);
     const size_t nb = stft_blocks(soff, nclips, maxf);
@@ -660,8 +719,15 @@ int nhans_stft_features(nhans_ctx* c, const float* wav, const int64_t* soff, int
     return stft_impl(c, wav, soff, nclips, maxf, logmag, phase, tabs, blocks, nullptr, s);
 }
 
-int nhans_embed(nhans_ctx* c, const float* ctx_lm, int n, float* emb_out, void* stream) {
-    int rc = check_ctx(c); if (rc) return rc;
+int nhans_stft_features(nhans_ctx* c, const float* wav, const int64_t* soff, int nclips, int maxf,
+                        float* logmag, float* phase, void* stream) {
+    Call call(c, stream);
+    if (call.rc) return call.rc;
+    return call.finish(stft_features_body(c, wav, soff, nclips, maxf, logmag, phase, stream));
+}
+
+static int embed_body(nhans_ctx* c, const float* ctx_lm, int n, float* emb_out, void* stream) {
+    int rc = NHANS_OK;
     if (!ctx_lm || !emb_out || n < 0) return fail(NHANS_EINVAL, "null argument");
     hipStream_t s = static_cast<hipStream_t>(stream);
     const size_t nb = tower_buf_floats(c);
@@ -670,9 +736,15 @@ int nhans_embed(nhans_ctx* c, const float* ctx_lm, int n, float* emb_out, void* 
     return embed_impl(c, ctx_lm, n, emb_out, X, A, Y, s);
 }
 
-int nhans_mask_net(nhans_ctx* c, const float* logmag, const int64_t* foff, int nclips, const float* ea,
+int nhans_embed(nhans_ctx* c, const float* ctx_lm, int n, float* emb_out, void* stream) {
+    Call call(c, stream);
+    if (call.rc) return call.rc;
+    return call.finish(embed_body(c, ctx_lm, n, emb_out, stream));
+}
+
+static int mask_net_body(nhans_ctx* c, const float* logmag, const int64_t* foff, int nclips, const float* ea,
                    const float* eb, float* logits, float* denoised, void* stream) {
-    int rc = check_ctx(c); if (rc) return rc;
+    int rc = NHANS_OK;
     if (!logmag || !foff || !ea || !eb || !denoised || nclips < 1) return fail(NHANS_EINVAL, "null argument");
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int64_t total = foff[nclips];
@@ -684,9 +756,16 @@ int nhans_mask_net(nhans_ctx* c, const float* logmag, const int64_t* foff, int n
     return mask_net_impl(c, logmag, foff, nclips, ea, eb, logits, denoised, sb, wf, s);
 }
 
-int nhans_debug_block_output(nhans_ctx* c, const float* logmag, const int64_t* foff, int nclips, const float* ea,
+int nhans_mask_net(nhans_ctx* c, const float* logmag, const int64_t* foff, int nclips, const float* ea,
+                   const float* eb, float* logits, float* denoised, void* stream) {
+    Call call(c, stream);
+    if (call.rc) return call.rc;
+    return call.finish(mask_net_body(c, logmag, foff, nclips, ea, eb, logits, denoised, stream));
+}
+
+static int debug_block_output_body(nhans_ctx* c, const float* logmag, const int64_t* foff, int nclips, const float* ea,
                              const float* eb, int64_t frame0, int nframes, int block, float* out, void* stream) {
-    int rc = check_ctx(c); if (rc) return rc;
+    int rc = NHANS_OK;
     if (!logmag || !foff || !ea || !eb || !out || block < 0 || block > 8) return fail(NHANS_EINVAL, "bad argument");
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int64_t total = foff[nclips];
@@ -707,9 +786,16 @@ int nhans_debug_block_output(nhans_ctx* c, const float* logmag, const int64_t* f
     return NHANS_OK;
 }
 
-int nhans_istft(nhans_ctx* c, const float* logmag, const float* phase, const int64_t* foff, int nclips,
+int nhans_debug_block_output(nhans_ctx* c, const float* logmag, const int64_t* foff, int nclips, const float* ea,
+                             const float* eb, int64_t frame0, int nframes, int block, float* out, void* stream) {
+    Call call(c, stream);
+    if (call.rc) return call.rc;
+    return call.finish(debug_block_output_body(c, logmag, foff, nclips, ea, eb, frame0, nframes, block, out, stream));
+}
+
+static int istft_body(nhans_ctx* c, const float* logmag, const float* phase, const int64_t* foff, int nclips,
                 const int64_t* ooff, float* wav_out, void* stream) {
-    int rc = check_ctx(c); if (rc) return rc;
+    int rc = NHANS_OK;
     if (!logmag || !phase || !foff || !ooff || !wav_out) return fail(NHANS_EINVAL, "null argument");
     hipStream_t s = static_cast<hipStream_t>(stream);
     const size_t nb = istft_blocks(foff, nclips);
@@ -719,11 +805,18 @@ int nhans_istft(nhans_ctx* c, const float* logmag, const float* phase, const int
     return istft_impl(c, logmag, phase, foff, nclips, ooff, wav_out, tabs, blocks, s);
 }
 
-int nhans_enhance_clips(nhans_ctx* c, const float* mix, const int64_t* moff, int nclips, const float* ca,
+int nhans_istft(nhans_ctx* c, const float* logmag, const float* phase, const int64_t* foff, int nclips,
+                const int64_t* ooff, float* wav_out, void* stream) {
+    Call call(c, stream);
+    if (call.rc) return call.rc;
+    return call.finish(istft_body(c, logmag, phase, foff, nclips, ooff, wav_out, stream));
+}
+
+static int enhance_clips_body(nhans_ctx* c, const float* mix, const int64_t* moff, int nclips, const float* ca,
                         const int64_t* caoff, const float* cbw, const int64_t* cboff, float* den_wav,
                         float* mixed_wav, float* logmag_out, float* phase_out, float* logits_out, float* emb_out,
                         void* stream) {
-    int rc = check_ctx(c); if (rc) return rc;
+    int rc = NHANS_OK;
     if (!mix || !moff || !ca || !caoff || !cbw || !cboff || !den_wav || nclips < 1)
         return fail(NHANS_EINVAL, "null argument");
     hipStream_t s = static_cast<hipStream_t>(stream);
@@ -783,12 +876,74 @@ int nhans_enhance_clips(nhans_ctx* c, const float* mix, const int64_t* moff, int
     return NHANS_OK;
 }
 
+int nhans_enhance_clips(nhans_ctx* c, const float* mix, const int64_t* moff, int nclips, const float* ca,
+                        const int64_t* caoff, const float* cbw, const int64_t* cboff, float* den_wav,
+                        float* mixed_wav, float* logmag_out, float* phase_out, float* logits_out, float* emb_out,
+                        void* stream) {
+    Call call(c, stream);
+    if (call.rc) return call.rc;
+    return call.finish(enhance_clips_body(c, mix, moff, nclips, ca, caoff, cbw, cboff, den_wav, mixed_wav, logmag_out, phase_out, logits_out, emb_out, stream));
+}
+
+int nhans_take_status(nhans_ctx* c, int* flags_out, void* stream) {
+    int rc = check_ctx(c); if (rc) return rc;
+    if (!flags_out) return fail(NHANS_EINVAL, "null argument");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    int flags = 0;
+    HIP_TRY(hipMemcpyAsync(&flags, c->status_dev, sizeof(int), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemsetAsync(c->status_dev, 0, sizeof(int), s));
+    HIP_TRY(hipStreamSynchronize(s));
+    *flags_out = flags;
+    return NHANS_OK;
+}
+
+int nhans_debug_launch_probe(size_t dynamic_lds_bytes, void* stream) {
+    (void)take_launch_error(nullptr);
+    static unsigned long long probe_devices = 0;
+    if (dynamic_lds_bytes > 65536)
+        set_max_dynamic_lds(reinterpret_cast<const void*>(&launch_probe_kernel), dynamic_lds_bytes, &probe_devices, "launch_probe");
+    // (the launch is attempted even if the attribute was refused: both failures must surface)
+    NHANS_LAUNCH("launch_probe", launch_probe_kernel, dim3(1), dim3(64), dynamic_lds_bytes, static_cast<hipStream_t>(stream),
+                 static_cast<int*>(nullptr));
+    return launch_status();
+}
+
+uint32_t nhans_crc32c(uint32_t crc, const void* data, size_t n) {
+    // slicing-by-8 over the reflected Castagnoli polynomial 0x82F63B78
+    static const struct Tab {
+        uint32_t t[8][256];
+        Tab() {
+            for (uint32_t i = 0; i < 256; ++i) {
+                uint32_t c = i;
+                for (int k = 0; k < 8; ++k) c = (c & 1) ? (c >> 1) ^ 0x82F63B78u : c >> 1;
+                t[0][i] = c;
+            }
+            for (uint32_t i = 0; i < 256; ++i)
+                for (int s = 1; s < 8; ++s) t[s][i] = (t[s - 1][i] >> 8) ^ t[0][t[s - 1][i] & 0xFF];
+        }
+    } T;
+    const unsigned char* p = static_cast<const unsigned char*>(data);
+    uint32_t c = ~crc;
+    while (n >= 8) {
+        uint32_t lo, hi;
+        std::memcpy(&lo, p, 4);
+        std::memcpy(&hi, p + 4, 4);
+        lo ^= c;
+        c = T.t[7][lo & 0xFF] ^ T.t[6][(lo >> 8) & 0xFF] ^ T.t[5][(lo >> 16) & 0xFF] ^ T.t[4][lo >> 24] ^
+            T.t[3][hi & 0xFF] ^ T.t[2][(hi >> 8) & 0xFF] ^ T.t[1][(hi >> 16) & 0xFF] ^ T.t[0][hi >> 24];
+        p += 8;
+        n -= 8;
+    }
+    while (n--) c = T.t[0][(c ^ *p++) & 0xFF] ^ (c >> 8);
+    return ~c;
+}
+
 int nhans_profile_reset(nhans_ctx* c) {
     if (!c) return fail(NHANS_EINVAL, "null context");
     (void)hipSetDevice(c->device);
     (void)hipDeviceSynchronize();
     for (auto& kv : c->prof)
-        for (auto& ev : kv.second.pending) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
+        for (auto& ev : kv.second.pending) { c->event_pool.push_back(ev.first); c->event_pool.push_back(ev.second); }
     c->prof.clear();
     return NHANS_OK;
 }
@@ -804,8 +959,8 @@ int nhans_profile_json(nhans_ctx* c, char* buf, size_t buflen) {
             (void)hipEventSynchronize(ev.second);
             float ms = 0.f;
             if (hipEventElapsedTime(&ms, ev.first, ev.second) == hipSuccess) e.ms += ms;
-            (void)hipEventDestroy(ev.first);
-            (void)hipEventDestroy(ev.second);
+            c->event_pool.push_back(ev.first);
+            c->event_pool.push_back(ev.second);
         }
         e.pending.clear();
         char line[256];

@@ -8,6 +8,38 @@ namespace nhans {
 constexpr int kWin = 400, kHop = 160, kBins = 201, kMixWin = 35, kCtxFrames = 200, kEmb = 512;
 constexpr int kCenter = kMixWin / 2;
 
+// Developer tooling (cycle stamps, timing ablations that compute WRONG results, kernel-choice
+// switches read from the environment) exists only in a `make DEV=1` build (-DNHANS_DEV); the
+// default library contains none of it.
+#ifdef NHANS_DEV
+constexpr bool kDev = true;
+int dev_ablate();          // getenv("NHANS_ABLATE"), read once
+bool dev_halo2d_enabled(); // getenv("NHANS_HALO2D") != "0"
+#else
+constexpr bool kDev = false;
+constexpr int dev_ablate() { return 0; }
+constexpr bool dev_halo2d_enabled() { return true; }
+#endif
+
+// ---------------------------------------------------------------------------------------------
+// Launch-error channel (launch_status.hip).  Every launcher calls note_launch() right after its
+// hipLaunchKernelGGL and set_max_dynamic_lds() before a launch that needs more than 64 KB of LDS;
+// the first failure of the calling thread is kept until the C-ABI entry point collects it with
+// take_launch_error() and returns NHANS_EHIP.  Nothing is launched silently wrong.
+void note_launch(const char* kernel);
+// hipFuncAttributeMaxDynamicSharedMemorySize is a per-DEVICE attribute: `done_mask` (one static per
+// kernel instantiation) has one bit per device id.
+void set_max_dynamic_lds(const void* fn, size_t bytes, unsigned long long* done_mask, const char* kernel);
+hipError_t take_launch_error(const char** kernel);
+#define NHANS_LAUNCH(NAME, KERNEL, GRID, BLOCK, LDS, STREAM, ...)                                  \
+    do {                                                                                           \
+        hipLaunchKernelGGL(KERNEL, GRID, BLOCK, LDS, STREAM, __VA_ARGS__);                         \
+        ::nhans::note_launch(NAME);                                                                \
+    } while (0)
+
+// bit set in *sat by the split-f16 writers when an activation does not fit f16 (|v| >= 65504 or NaN)
+constexpr int kSatActivation = 1;
+
 // Division by a runtime constant for numerators < 2^31 (Granlund-Montgomery round-up form).
 struct FastDiv {
     uint32_t d, mul, sh;
@@ -69,9 +101,10 @@ struct ConvArgs {
     int out_split;         // write `out` as split NHWC (ldo = N words per pixel) instead of f32
     int id_split;          // id_mode 1 tensor is split NHWC
     const float* ws;       // prec 1: per-channel power-of-two that undoes the weight pre-scaling
+    int* sat;              // prec 1: device flag word, kSatActivation is OR-ed in when a stored activation saturates
     int variant;           // 0: 128-pixel / 4-wave register-staged kernel, 1: 256-pixel / 8-wave LDS-DMA kernel,
                            // 2: LDS-DMA kernel with halo reuse across the KW taps where the conv allows it
-    long long* dbg;        // optional (dev tool): 4 s_memtime stamps per workgroup [start, loop, epilogue, end]
+    long long* dbg;        // NHANS_DEV builds only: 4 s_memtime stamps per workgroup [start, loop, epilogue, end]
     FastDiv fdHoWo, fdWo;
     FastDiv fdWP;          // Wo + KW - 1 (filled in by launch_conv_igemm_halo)
     // split-K scratch (conv_igemm_dma.hip; null = never split): partial accumulator tiles and one
@@ -108,6 +141,7 @@ struct DirectArgs {     // convolution of a 1-channel image into 64 channels, sa
     const float* tf;    // [Ho*Wo,64] nullable
     int relu;
     int out_split;      // write split NHWC (hi/lo f16) instead of f32
+    int* sat;           // as ConvArgs::sat
     FastDiv fdHoWo, fdWo;
 };
 void launch_direct_conv64(const DirectArgs& a, hipStream_t s);

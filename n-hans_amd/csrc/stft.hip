@@ -104,8 +104,8 @@ __global__ void __launch_bounds__(256) stft_features_kernel(
 void launch_stft(const float* wav, ClipTable t, const int* block_clip, const int* block_f0, int nblocks,
                  const float* tw400, const float* window, float* logmag, float* phase, hipStream_t s) {
     if (nblocks <= 0) return;
-    hipLaunchKernelGGL(stft_features_kernel, dim3(nblocks), dim3(256), 0, s, wav, t, block_clip, block_f0,
-                       reinterpret_cast<const cplx*>(tw400), window, logmag, phase);
+    NHANS_LAUNCH("stft_features", stft_features_kernel, dim3(nblocks), dim3(256), 0, s, wav, t, block_clip, block_f0,
+                 reinterpret_cast<const cplx*>(tw400), window, logmag, phase);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -205,14 +205,10 @@ void launch_istft(const float* logmag, const float* phase, ClipTable t, const in
     if (nblocks <= 0) return;
     constexpr size_t lds = (400 + 4 * kFpw * kTFrame + 4 * kFpw * kBins) * sizeof(cplx) +
                            (kWin + (kIstftHopsPerBlock + 2) * kWin) * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&istft_ola_kernel),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
-    }
-    hipLaunchKernelGGL(istft_ola_kernel, dim3(nblocks), dim3(256), lds, s, logmag, phase, t, block_clip,
-                       block_h0, reinterpret_cast<const cplx*>(tw400), wsyn, wav_out);
+    static unsigned long long attr_devices = 0;
+    set_max_dynamic_lds(reinterpret_cast<const void*>(&istft_ola_kernel), lds, &attr_devices, "istft_ola");
+    NHANS_LAUNCH("istft_ola", istft_ola_kernel, dim3(nblocks), dim3(256), lds, s, logmag, phase, t, block_clip,
+                 block_h0, reinterpret_cast<const cplx*>(tw400), wsyn, wav_out);
 }
 
 }  // namespace nhans

@@ -2,6 +2,7 @@
 PyTorch is used only for device memory and streams; all arithmetic runs in the HIP library."""
 import ctypes
 import os
+import warnings
 
 import numpy as np
 import torch
@@ -65,6 +66,13 @@ class Engine:
     def set_option(self, key, value):
         hip.check(self.lib.nhans_set_option(self.handle, key.encode(), int(value)))
 
+    def take_status(self):
+        """Waits for the current stream; returns and clears the sticky device status bits
+        (hip.STATUS_SATURATED: a split-f16 activation left the f16 range and was clamped)."""
+        flags = ctypes.c_int(0)
+        hip.check(self.lib.nhans_take_status(self.handle, ctypes.byref(flags), self._stream()))
+        return flags.value
+
     def _stream(self):
         return ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
@@ -122,9 +130,13 @@ class Engine:
     def enhance_device(self, mix_t, mix_off, ca_t, ca_off, cb_t, cb_off, want_mixed=False, taps=False):
         """All inputs already in HBM.  Returns dict of device tensors."""
         n = len(mix_off) - 1
-        total = sum(int(self.lib.nhans_num_frames(mix_off[i + 1] - mix_off[i])) for i in range(n))
-        res = {"denoised_wav": torch.empty(mix_off[-1], dtype=torch.float32, device=self.device)}
-        res["mixed_wav"] = torch.empty_like(res["denoised_wav"]) if want_mixed else None
+        nfr = [int(self.lib.nhans_num_frames(mix_off[i + 1] - mix_off[i])) for i in range(n)]
+        if any(t == 0 for t in nfr):
+            # (the reference dies on such a clip too: its STFT has no frames to stack)
+            raise ValueError("mixture clip %d has fewer than %d samples: no STFT frame" % (nfr.index(0), spec.WIN))
+        total = sum(nfr)
+        res = {"denoised_wav": torch.zeros(mix_off[-1], dtype=torch.float32, device=self.device)}
+        res["mixed_wav"] = torch.zeros_like(res["denoised_wav"]) if want_mixed else None
         if taps:
             for k in ("logmag", "phase", "logits"):
                 res[k] = torch.empty((total, spec.BINS), dtype=torch.float32, device=self.device)
@@ -142,6 +154,16 @@ class Engine:
         ca_t, ca_off = self._dev(ctx_a)
         cb_t, cb_off = self._dev(ctx_b)
         res = self.enhance_device(mix_t, mix_off, ca_t, ca_off, cb_t, cb_off, want_mixed, taps)
+        if self.take_status() & hip.STATUS_SATURATED and self.precision == "f16x3":
+            # the split-f16 layout holds |activation| < 65504; these weights/inputs exceed it somewhere:
+            # redo the batch on the exact f32 matrix-core path (same library, no CPU involved)
+            warnings.warn("N-HANS f16x3 path: an activation left the f16 range; batch recomputed in f32 MFMA mode")
+            self.set_precision("f32")
+            try:
+                res = self.enhance_device(mix_t, mix_off, ca_t, ca_off, cb_t, cb_off, want_mixed, taps)
+                self.take_status()
+            finally:
+                self.set_precision("f16x3")
         torch.cuda.synchronize(self.device)
         out = {"denoised_wav": [], "mixed_wav": []}
         den = res["denoised_wav"].cpu().numpy()

@@ -16,8 +16,9 @@ EXPORTS = [
     "nhans_abi_version", "nhans_last_error", "nhans_num_frames", "nhans_create", "nhans_destroy",
     "nhans_set_option", "nhans_workspace_bytes", "nhans_stft_features", "nhans_embed",
     "nhans_mask_net", "nhans_istft", "nhans_enhance_clips", "nhans_debug_block_output",
-    "nhans_profile_json", "nhans_profile_reset",
+    "nhans_profile_json", "nhans_profile_reset", "nhans_take_status", "nhans_debug_launch_probe", "nhans_crc32c",
 ]
+STATUS_SATURATED = 1
 
 _lib = None
 
@@ -56,11 +57,15 @@ def load():
                                              ctypes.c_int, vp, vp]
     lib.nhans_profile_json.argtypes = [vp, ctypes.c_char_p, ctypes.c_size_t]
     lib.nhans_profile_reset.argtypes = [vp]
+    lib.nhans_take_status.argtypes = [vp, ctypes.POINTER(ctypes.c_int), vp]
+    lib.nhans_debug_launch_probe.argtypes = [ctypes.c_size_t, vp]
+    lib.nhans_crc32c.argtypes = [ctypes.c_uint32, vp, ctypes.c_size_t]
+    lib.nhans_crc32c.restype = ctypes.c_uint32
     for name in ("nhans_create", "nhans_set_option", "nhans_stft_features", "nhans_embed", "nhans_mask_net",
                  "nhans_istft", "nhans_enhance_clips", "nhans_debug_block_output", "nhans_profile_json",
-                 "nhans_profile_reset"):
+                 "nhans_profile_reset", "nhans_take_status", "nhans_debug_launch_probe"):
         getattr(lib, name).restype = ctypes.c_int
-    if lib.nhans_abi_version() != 1:
+    if lib.nhans_abi_version() != 2:
         raise NhansError("libnhans_hip.so ABI version mismatch")
     _lib = lib
     return lib

@@ -40,7 +40,8 @@ def verify(kind, model_dir="./trained_model", check_hash=True):
                 h.update(chunk)
         if h.hexdigest() != sha:
             raise ValueError("%s: sha256 %s does not match the reference's %s" % (data, h.hexdigest(), sha))
-    return weights.load_checkpoint(prefix, kind)
+    # (--no-hash skips both integrity checks: the file hash and the per-tensor crc32c of the index)
+    return weights.load_checkpoint(prefix, kind, verify_crc=check_hash)
 
 
 def _main(kind, argv):

@@ -21,59 +21,66 @@ SNRS_SEPARATOR = [-5, -3, -1, 0, 1, 3, 5]   # SS/apply.py:101
 
 
 def _fit_length(noise, n):
-    """Repeat the noise if it is shorter than the speech, cut it if longer (SN/apply.py:58-72)."""
-    nse = noise
-    while n - len(nse) > 0:
-        diff = n - len(nse)
-        nse = np.concatenate([nse, noise[:diff]], axis=0)
-    if n - len(noise) < 0:
-        nse = noise[:n]
-    return nse
+    """A noise recording as long as the speech: whole repetitions plus a head piece when it is
+    shorter, its first n samples when it is longer (what SN/apply.py:58-72 arrives at by repeated
+    concatenation; an empty recording stays empty there too)."""
+    m = len(noise)
+    if m >= n or m == 0:
+        return noise[:n]
+    reps, rest = divmod(n, m)
+    return np.concatenate([noise] * reps + [noise[:rest]], axis=0)
 
 
-def _power(x):
-    return sum(abs(x) * abs(x)) / x.shape[0]
+def _mean_power(x):
+    """Mean square of a float32 recording, accumulated the way the reference does it: one sample
+    after the other in float32 (its builtin sum() over numpy scalars; np.add.accumulate on a 1-D
+    float32 array performs the same left-to-right additions, without the per-element Python cost)."""
+    sq = np.abs(x) * np.abs(x)
+    if sq.dtype != np.float32 or sq.ndim != 1 or len(sq) == 0:
+        return sum(sq) / x.shape[0]
+    return np.add.accumulate(sq)[-1] / x.shape[0]
 
 
-def domixing(cleansamples, noisepossamples, noisenegsamples, snr_pos, snr_neg):
-    """Denoiser mixing (SN/apply.py:56-104).  Returns (mixed, target, K_pos, K_neg,
-    noise_pos_signal, noise_neg_signal)."""
-    nse_pos = _fit_length(noisepossamples, len(cleansamples))
-    nse_neg = _fit_length(noisenegsamples, len(cleansamples))
-    sig = cleansamples
-    psignal, pnoise_pos, pnoise_neg = _power(sig), _power(nse_pos), _power(nse_neg)
-    if pnoise_pos == 0:
-        K_pos = 1
-    else:
-        K_pos = np.sqrt((psignal / pnoise_pos) * pow(10, -snr_pos / 10.0))
-    if pnoise_neg == 0:
-        K_neg = 1
-    else:
-        K_neg = np.sqrt((psignal / pnoise_neg) * pow(10, -snr_neg / 10.0))
-    noise_pos_scaled = K_pos * nse_pos
-    noise_neg_scaled = K_neg * nse_neg
-    mixed = sig + noise_pos_scaled + noise_neg_scaled
-    mixed = mixed / (max(abs(mixed)) + 0.000001)
-    target = sig + noise_pos_scaled
-    target = target / (max(abs(mixed)) + 0.000001)          # sic: the normalised `mixed`
-    noise_pos_signal = noise_pos_scaled / (max(abs(mixed)) + 0.000001)
-    noise_neg_signal = noise_neg_scaled / (max(abs(mixed)) + 0.000001)
-    return mixed, target, K_pos, K_neg, noise_pos_signal, noise_neg_signal
+def _gain_for_snr(p_speech, p_noise, snr_db):
+    """Factor on the noise that puts it snr_db below the speech; silence is left alone (gain 1)."""
+    if p_noise == 0:
+        return 1
+    return np.sqrt((p_speech / p_noise) * pow(10, -snr_db / 10.0))
 
 
-def domixing_separator(cleansamples, noisesamples, snr):
-    """Separator mixing (SS/apply.py:54-79).  Returns (mixed, K)."""
-    nse = _fit_length(noisesamples, len(cleansamples))
-    sig = cleansamples
-    psignal, pnoise = _power(sig), _power(nse)
-    if pnoise == 0:
-        K = 1
-    else:
-        K = (psignal / pnoise) * pow(10, -snr / 10.0)
-    K = np.sqrt(K)
-    mixed = sig + K * nse
-    mixed = mixed / (max(abs(mixed)) + 0.000001)
-    return mixed, K
+def _peak(x):
+    return np.max(np.abs(x)) + 0.000001
+
+
+def domixing(speech, noise_keep, noise_drop, snr_keep_db, snr_drop_db):
+    """Three-way mixture of the denoiser (behaviour of SN/apply.py:56-104): speech, the noise the
+    model is told to KEEP (positive conditioning) and the one it is told to DROP (negative), each
+    noise brought to its SNR against the speech.  Returns (mixture, target, gain_keep, gain_drop,
+    keep_signal, drop_signal) where target = speech + kept noise.
+
+    Quirk preserved: only the mixture is peak-normalised by its own peak; the other three signals
+    are divided by the peak of the ALREADY normalised mixture (~1), not by the original peak."""
+    n = len(speech)
+    keep = _fit_length(noise_keep, n)
+    drop = _fit_length(noise_drop, n)
+    p_speech = _mean_power(speech)
+    gain_keep = _gain_for_snr(p_speech, _mean_power(keep), snr_keep_db)
+    gain_drop = _gain_for_snr(p_speech, _mean_power(drop), snr_drop_db)
+    keep_scaled = gain_keep * keep
+    drop_scaled = gain_drop * drop
+    raw = speech + keep_scaled + drop_scaled
+    mixture = raw / _peak(raw)
+    unit = _peak(mixture)
+    return mixture, (speech + keep_scaled) / unit, gain_keep, gain_drop, keep_scaled / unit, drop_scaled / unit
+
+
+def domixing_separator(target_speech, interferer, snr_db):
+    """Two-speaker mixture of the separator (behaviour of SS/apply.py:54-79).  Returns
+    (mixture, gain) with the mixture peak-normalised."""
+    other = _fit_length(interferer, len(target_speech))
+    gain = _gain_for_snr(_mean_power(target_speech), _mean_power(other), snr_db)
+    raw = target_speech + gain * other
+    return raw / _peak(raw), gain
 
 
 def eval_snrs(cleanpath):
@@ -85,8 +92,8 @@ def eval_snrs(cleanpath):
 
 
 def _normalise(x):
-    with np.errstate(over="ignore"):
-        return (x / (max(abs(x)) + 0.000001)).astype(np.float32)
+    with np.errstate(over="ignore"):       # (int16 abs(-32768) wraps, as in the reference)
+        return (x / (np.max(np.abs(x)) + 0.000001)).astype(np.float32)
 
 
 def combine_signals(read_wav, cleanpath, noisepospath, noisenegpath, snrs=None):

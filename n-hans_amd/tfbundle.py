@@ -11,6 +11,13 @@ published on-disk layout:
             key ""   -> BundleHeaderProto, key <tensor name> -> BundleEntryProto
             {1: dtype, 2: shape{2: dim{1: size}}, 3: shard_id, 4: offset, 5: size, 6: crc32c}
   .data-* = raw little-endian tensors at `offset`.
+
+Integrity: every table block carries a 5-byte trailer (compression type + masked CRC-32C of block
+and type byte) and every BundleEntryProto the masked CRC-32C of its tensor bytes
+(mask(c) = rotr15(c) + 0xa282ead8).  Both are verified here -- the block trailers always, the
+tensors by load_checkpoint(verify_crc=True).  The implementation is pinned to TensorFlow-written
+values by the shipped `.index` files (tests/test_host.py: all their block trailers, and the one
+tensor whose bytes are known, the separator's int32 scalar `Variable` == 0).
 """
 import os
 import struct
@@ -50,9 +57,49 @@ def _block_entries(raw):
     return out
 
 
+_CRC_TABLE = None
+
+
+def crc32c(data, crc=0):
+    """CRC-32C (Castagnoli, reflected 0x82F63B78) of a bytes-like object.  Large buffers go through
+    the library's host helper `nhans_crc32c` when it is built; the table loop below is the same
+    function in plain Python."""
+    global _CRC_TABLE
+    mv = memoryview(data).cast("B")
+    if len(mv) >= 4096:
+        try:
+            from . import hip
+            lib = hip.load()
+            buf = np.frombuffer(mv, dtype=np.uint8)
+            return int(lib.nhans_crc32c(crc, buf.ctypes.data, len(buf)))
+        except (ImportError, OSError, RuntimeError):
+            pass
+    if _CRC_TABLE is None:
+        tab = []
+        for i in range(256):
+            c = i
+            for _ in range(8):
+                c = (c >> 1) ^ 0x82F63B78 if c & 1 else c >> 1
+            tab.append(c)
+        _CRC_TABLE = tab
+    c = crc ^ 0xFFFFFFFF
+    for b in mv:
+        c = _CRC_TABLE[(c ^ b) & 0xFF] ^ (c >> 8)
+    return c ^ 0xFFFFFFFF
+
+
+def masked_crc32c(data):
+    """What TensorFlow stores: crc32c::Mask(crc32c::Value(data))."""
+    c = crc32c(data)
+    return (((c >> 15) | (c << 17)) + 0xA282EAD8) & 0xFFFFFFFF
+
+
 def _read_block(data, offset, size):
     if data[offset + size] != 0:
         raise ValueError("compressed table blocks are not supported")
+    stored = struct.unpack_from("<I", data, offset + size + 1)[0]
+    if masked_crc32c(data[offset:offset + size + 1]) != stored:
+        raise ValueError("table block at offset %d: crc32c mismatch (corrupt .index)" % offset)
     return _block_entries(data[offset:offset + size])
 
 
@@ -130,10 +177,11 @@ def is_lfs_pointer(path):
         return False
 
 
-def load_checkpoint(prefix):
+def load_checkpoint(prefix, verify_crc=True):
     """Read every float/int tensor of a bundle -> OrderedDict name -> ndarray.  Raises
     FileNotFoundError when the data shard is missing or is a git-LFS pointer (as shipped in
-    the reference tree)."""
+    the reference tree) and ValueError when a tensor's bytes do not match the masked CRC-32C the
+    index records for it (verify_crc=False skips that check)."""
     entries = read_index(prefix + ".index")
     dpath = data_path(prefix)
     if not os.path.exists(dpath) or is_lfs_pointer(dpath):
@@ -150,6 +198,10 @@ def load_checkpoint(prefix):
             if dt is None:
                 continue
             f.seek(e["offset"])
-            arr = np.frombuffer(f.read(e["size"]), dtype=dt)
+            raw = f.read(e["size"])
+            if verify_crc and masked_crc32c(raw) != e["crc32c"]:
+                raise ValueError("%s: tensor %s does not match its crc32c in the index (corrupt or wrong data shard)"
+                                 % (dpath, name))
+            arr = np.frombuffer(raw, dtype=dt)
             out[name] = arr.reshape(e["shape"]).copy()
     return out

@@ -73,9 +73,10 @@ def synthetic_weights(kind=spec.DENOISER, seed=7):
     return out
 
 
-def load_checkpoint(prefix, kind):
-    """Load a real TF bundle (user-supplied LFS blob) and check it against the inventory."""
-    raw = tfbundle.load_checkpoint(prefix)
+def load_checkpoint(prefix, kind, verify_crc=True):
+    """Load a real TF bundle (user-supplied LFS blob) and check it against the inventory and the
+    per-tensor CRCs of its index."""
+    raw = tfbundle.load_checkpoint(prefix, verify_crc)
     out = OrderedDict()
     for name, shape in spec.variable_shapes(kind).items():
         if name not in raw:

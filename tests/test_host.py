@@ -50,11 +50,41 @@ def test_bundle_reader_roundtrip_and_lfs_pointer(tmp_path, weights_separator):
             buf[e["offset"]:e["offset"] + e["size"]] = weights_separator[n].tobytes()
     with open(prefix + ".data-00000-of-00001", "wb") as f:
         f.write(buf)
-    got = weights.load_checkpoint(prefix, "separator")
+    # the shipped index records the crc32c of the TRAINED tensors: synthetic bytes must be refused ...
+    with pytest.raises(ValueError, match="crc32c"):
+        weights.load_checkpoint(prefix, "separator")
+    # ... and load when the check is switched off
+    got = weights.load_checkpoint(prefix, "separator", verify_crc=False)
     assert list(got) == list(spec.variable_shapes("separator"))
     for n in got:
         assert np.array_equal(got[n], weights_separator[n])
-    assert int(tfbundle.load_checkpoint(prefix)["Variable"]) == 545000
+    assert int(tfbundle.load_checkpoint(prefix, verify_crc=False)["Variable"]) == 545000
+
+
+def test_crc32c_pinned_to_tensorflow_written_values(tmp_path, lib_built):
+    """The reference's own `.index` files carry TF-written masked CRC-32Cs: one per table block
+    (verified by read_index) and one per tensor.  The only tensor whose bytes are known without the
+    LFS blob is the separator's int32 scalar `Variable`, which is 0."""
+    assert tfbundle.crc32c(b"123456789") == 0xE3069283                      # the CRC-32C check value
+    ent = tfbundle.read_index(os.path.join(GOLDEN, "separator.index"))      # block trailers verified inside
+    assert ent["Variable"]["crc32c"] == tfbundle.masked_crc32c(struct.pack("<i", 0))
+    assert ent["Variable"]["crc32c"] != tfbundle.masked_crc32c(struct.pack("<i", 545000))
+    # a flipped byte inside a data block of the index is caught by its trailer
+    raw = bytearray(open(os.path.join(GOLDEN, "denoiser.index"), "rb").read())
+    raw[100] ^= 0x40
+    bad = str(tmp_path / "bad.index")
+    open(bad, "wb").write(raw)
+    with pytest.raises(ValueError, match="crc32c"):
+        tfbundle.read_index(bad)
+    # the library's slicing-by-8 host helper == the plain table loop
+    blob = np.random.default_rng(3).integers(0, 256, 100003, dtype=np.uint8).tobytes()
+    lib = hip.load()
+    buf = np.frombuffer(blob, dtype=np.uint8)
+    fast = lib.nhans_crc32c(0, buf.ctypes.data, len(buf))
+    slow = 0
+    for i in range(0, len(blob), 1000):          # below the 4096-byte switch: pure Python, chained
+        slow = tfbundle.crc32c(blob[i:i + 1000], slow)
+    assert fast == slow == tfbundle.crc32c(blob)
 
 
 def test_synthetic_weights_deterministic_and_shared():
@@ -162,7 +192,7 @@ def test_library_exports_every_declared_symbol(lib_built):
     for name in declared:
         assert hasattr(lib, name), name
     h = hip.load()
-    assert h.nhans_abi_version() == 1
+    assert h.nhans_abi_version() == 2
     assert h.nhans_num_frames(399) == 0 and h.nhans_num_frames(400) == 1 and h.nhans_num_frames(159920) == 998
     bad = ctypes.create_string_buffer(b"x" * 64, 64)
     out = ctypes.c_void_p()
