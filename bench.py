@@ -7,7 +7,13 @@ inputs already resident in HBM, including (N > 1) the single RCCL all-gather of 
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-Prints ONE JSON line on rank 0 (contract in the task statement).
+Default workload = BASELINE.json configs[2], the largest single-GPU configuration: 256 synthetic
+10 s mixtures per GPU (255,488 frame windows, 2.65 PFLOP per step).  `--clips-per-gpu 1` is
+configs[1].  Prints ONE JSON line on rank 0 (contract in the task statement).
+
+The timed region runs with the library's per-launch profiling events OFF.  The per-kernel figures
+(`roofline`, `hbm_kernels`, `kernel_ms_per_step`) come from ONE extra pass run right after the timed
+region with hipEvents recorded by the library on the launch stream around every launch.
 """
 import argparse
 import json
@@ -26,31 +32,38 @@ from nhans_amd.apply import normalise, trim_to_frames  # noqa: E402
 
 F32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 F16_MFMA_PEAK_TFLOPS = 2500.0     # dense f16 MFMA peak; the split mode executes 3 products per MAC
-HBM_PEAK_GBS = 8000.0
+HBM_PEAK_GBS = 8000.0             # spec; 6,290 GB/s is what a float4 copy achieves (same guide)
+HBM_ACHIEVABLE_GBS = 6290.0
+PMC_SUMMARY = os.path.join("profiles", "r02", "pmc_summary_bench_256clips.json")
 
 
 def parse():
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
-    p.add_argument("--steps", type=int, default=5)
-    p.add_argument("--warmup", type=int, default=2)
-    p.add_argument("--clips-per-gpu", type=int, default=1,
-                   help="1 = BASELINE configs[1] (single 10 s clip); 256 = configs[2]")
+    p.add_argument("--steps", type=int, default=3)
+    p.add_argument("--warmup", type=int, default=1)
+    p.add_argument("--clips-per-gpu", type=int, default=256,
+                   help="256 = BASELINE configs[2] (default, the headline single-GPU config); 1 = configs[1]")
+    p.add_argument("--distinct", type=int, default=0, help="distinct synthetic clips (0 = all of them)")
     p.add_argument("--seconds", type=float, default=10.0)
     p.add_argument("--kind", default="denoiser", choices=["denoiser", "separator"])
     p.add_argument("--frames-per-chunk", type=int, default=0)
     p.add_argument("--precision", default="f16x3", choices=["f32", "f16x3"])
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--no-kernel-pass", action="store_true", help="skip the extra profiled pass (rocprofv3 runs)")
     p.add_argument("--cpu-frames", type=int, default=32, help="frames of the CPU baseline sample")
     p.add_argument("--cpu-threads", type=int, default=0, help="0 = min(host cores, 64)")
+    p.add_argument("--share-device0", action="store_true",
+                   help="functional check of the N > 1 code path on a one-GPU box: every rank uses device 0 and the "
+                        "all-gather runs over gloo (RCCL refuses two ranks on one device); not a measurement")
     return p.parse_args()
 
 
-def make_batch(kind, rank, clips, seconds):
-    """Synthetic clips for this rank, through the reference's normalise/trim (apply.py)."""
+def make_batch(kind, rank, clips, seconds, distinct):
+    """Synthetic clips for this rank, through the reference's normalise/trim (apply.py).  Every clip
+    is its own seeded signal unless --distinct asks for fewer (then they repeat cyclically)."""
     mixes, ca, cb = [], [], []
-    # only a few distinct clips are synthesised; they are tiled to the requested batch size
-    distinct = min(clips, 4)
+    distinct = clips if distinct <= 0 else min(clips, distinct)
     for i in range(distinct):
         cid = rank * clips + i
         mixes.append(trim_to_frames(normalise(synth.mixture(cid, seconds))))
@@ -61,11 +74,11 @@ def make_batch(kind, rank, clips, seconds):
             ca.append(normalise(synth.speaker_context(cid, low=True)))    # interferer (--neg)
             cb.append(normalise(synth.speaker_context(cid, low=False)))   # target (--pos)
     rep = lambda lst: [lst[i % distinct] for i in range(clips)]
-    return rep(mixes), rep(ca), rep(cb)
+    return rep(mixes), rep(ca), rep(cb), distinct
 
 
-def cpu_baseline(W, kind, mix, ca, cb, frames, hip_wav, threads):
-    """Reference-faithful float32 CPU path (oracle/torch_ref.py) on a bounded sample."""
+def cpu_baseline(W, kind, mix, ca, cb, frames, threads):
+    """Reference-faithful float32 CPU path (oracle/torch_ref.py) on a bounded sample of the workload."""
     from oracle.torch_ref import TorchRef
     torch.set_num_threads(threads or min(os.cpu_count() or 1, 64))
     ref = TorchRef(W, kind, torch.float32)
@@ -75,9 +88,9 @@ def cpu_baseline(W, kind, mix, ca, cb, frames, hip_wav, threads):
     n = out["frames_done"]
     res = {"value": (n / dt) / 100.0, "unit": "audio-seconds/s", "cores": torch.get_num_threads(), "kind": "port",
            "frames_per_s": n / dt,
-           "sample": "first %d-frame minibatch of clip 0, float32 torch-CPU restatement in reference-faithful mode "
-                     "(both 200-frame contexts tiled per frame, embedding towers re-run inside the minibatch, "
-                     "SN/apply.py:381-387,440-446), %.1f s" % (n, dt)}
+           "sample": "first %d-frame minibatch of clip 0 of the workload, float32 torch-CPU restatement in "
+                     "reference-faithful mode (both 200-frame contexts tiled per frame, embedding towers re-run "
+                     "inside the minibatch, SN/apply.py:381-387,440-446), %.1f s" % (n, dt)}
     # the same port with the embeddings computed once per clip (the restructuring of SURVEY F7 that the
     # HIP path also uses), extrapolated to the whole clip: separates that algorithmic saving from the hardware
     with torch.no_grad():
@@ -91,11 +104,26 @@ def cpu_baseline(W, kind, mix, ca, cb, frames, hip_wav, threads):
         ref.mask_net(win, ea.expand(len(win), -1), eb.expand(len(win), -1))
         t_batch = time.time() - t1
     res["dedup_embedding_value"] = (len(mix) / float(spec.FS)) / (t_tower + lm.shape[0] / float(len(win)) * t_batch)
-    # samples below (n-2)*160 depend only on frames < n
-    k = max((n - 2) * spec.HOP, 0)
-    cw = out["denoised_wav"].numpy()[:k]
-    rms = float(np.sqrt(np.mean((cw - hip_wav[:k]) ** 2))) if k else None
-    return res, rms
+    return res
+
+
+def rms_check(W, kind, eng, threads):
+    """Whole-waveform RMS of the HIP path against the float32 CPU restatement on a FULL short clip
+    (0.5 s = 48 frames: every frame, both clip edges, the complete overlap-add)."""
+    from oracle.torch_ref import TorchRef
+    torch.set_num_threads(threads or min(os.cpu_count() or 1, 64))
+    cid = 4242
+    mix = trim_to_frames(normalise(synth.mixture(cid, 0.5)))
+    if kind == "denoiser":
+        ca, cb = normalise(synth.silent()), normalise(synth.noise_context(cid))
+    else:
+        ca, cb = normalise(synth.speaker_context(cid, low=True)), normalise(synth.speaker_context(cid, low=False))
+    got = eng.enhance([mix], [ca], [cb], want_mixed=False)["denoised_wav"][0]
+    ref = TorchRef(W, kind, torch.float32).enhance(mix, ca, cb, faithful=False)["denoised_wav"].numpy()
+    assert got.shape == ref.shape
+    return {"rms": float(np.sqrt(np.mean((got - ref) ** 2))), "samples": int(len(ref)),
+            "clip": "full 0.5 s synthetic clip (48 frames), HIP waveform vs float32 torch-CPU restatement",
+            "tolerance": 1e-3}
 
 
 def main():
@@ -104,16 +132,21 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
+    if a.share_device0:
+        local = 0
     if world > 1:
         import torch.distributed as dist
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if a.share_device0:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
 
     W = weights.synthetic_weights(a.kind, 7)
     eng = engine.Engine(a.kind, W, device=local, frames_per_chunk=a.frames_per_chunk or None, precision=a.precision)
-    mixes, ca, cb = make_batch(a.kind, rank, a.clips_per_gpu, a.seconds)
+    mixes, ca, cb, distinct = make_batch(a.kind, rank, a.clips_per_gpu, a.seconds, a.distinct)
     mix_t, mix_off = eng._dev(mixes)
     ca_t, ca_off = eng._dev(ca)
     cb_t, cb_off = eng._dev(cb)
@@ -132,8 +165,6 @@ def main():
     for _ in range(a.warmup):
         res = step()
     torch.cuda.synchronize()
-    eng.set_option("profile", 1)
-    eng.profile_reset()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -144,62 +175,96 @@ def main():
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
-    prof = eng.profile()
-    eng.set_option("profile", 0)
+    status = eng.take_status()                  # sticky: covers every step above
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
+    # per-kernel pass: the same step once more with the library's hipEvent brackets on
+    prof, kpass_ms = {}, None
+    if rank == 0 and not a.no_kernel_pass:
+        eng.set_option("profile", 1)
+        eng.profile_reset()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        eng.enhance_device(mix_t, mix_off, ca_t, ca_off, cb_t, cb_off)
+        torch.cuda.synchronize()
+        kpass_ms = 1e3 * (time.perf_counter() - t1)
+        prof = eng.profile()
+        eng.set_option("profile", 0)
+
     if rank == 0:
+        ms_step = 1e3 * dt / a.steps
+        convs = {k: v for k, v in prof.items() if k.startswith("conv_igemm")}
+        conv_ms = sum(v["ms"] for v in convs.values())
+        conv_fl = sum(v["flops"] for v in convs.values())
+        conv_calls = sum(v["calls"] for v in convs.values())
+        peak = F16_MFMA_PEAK_TFLOPS if a.precision == "f16x3" else F32_MFMA_PEAK_TFLOPS
+        tflops = conv_fl / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
         # HBM bytes per conv launch: PMC counters cannot be read from inside this process; the committed
-        # summary of the separate rocprofv3 --pmc passes over this very command (profiles/r01, README
-        # there) is quoted when the workload is the one it was collected on.
+        # summary of the separate rocprofv3 --pmc passes over this very command (profiles/r02/README.md) is
+        # quoted when the workload is the one it was collected on.
         traffic, traffic_src = None, None
-        pmc = os.path.join(ROOT, "profiles", "r01", "pmc_summary_bench_f16x3_1step.json")
-        if a.precision == "f16x3" and a.clips_per_gpu == 1 and a.seconds == 10.0 and a.kind == "denoiser" and os.path.exists(pmc):
+        pmc = os.path.join(ROOT, PMC_SUMMARY)
+        if (a.precision == "f16x3" and a.clips_per_gpu == 256 and a.seconds == 10.0 and a.kind == "denoiser"
+                and os.path.exists(pmc)):
             rows = [v for k, v in json.load(open(pmc)).items() if "conv_igemm" in k]
             n = sum(v.get("dispatches_pass_c", 0) for v in rows)
             if n:
                 traffic = sum((v.get("derived_hbm_read_bytes_per_launch", 0.0) + v.get("derived_hbm_write_bytes_per_launch", 0.0))
                               * v.get("dispatches_pass_c", 0) for v in rows) / n
-                traffic_src = "profiles/r01/pmc_summary_bench_f16x3_1step.json (FETCH_SIZE x2 + WRITE_SIZE, bytes per conv launch)"
-        kname = "conv_igemm_h3" if a.precision == "f16x3" else "conv_igemm_f32"
-        peak = F16_MFMA_PEAK_TFLOPS if a.precision == "f16x3" else F32_MFMA_PEAK_TFLOPS
-        conv = prof.get(kname, {"ms": 0.0, "flops": 0.0, "calls": 0})
-        tflops = conv["flops"] / (conv["ms"] * 1e-3) / 1e12 if conv["ms"] > 0 else 0.0
-        stft = prof.get("stft_features", {"ms": 0.0, "bytes": 0.0})
-        istft = prof.get("istft_ola", {"ms": 0.0, "bytes": 0.0})
-        gbs = lambda e: e["bytes"] / (e["ms"] * 1e-3) / 1e9 if e["ms"] > 0 else 0.0
+                traffic_src = PMC_SUMMARY + " (FETCH_SIZE x2 + WRITE_SIZE, bytes per conv launch)"
+        gbs = lambda e: e["bytes"] / (e["ms"] * 1e-3) / 1e9 if e and e["ms"] > 0 else None
+        stft_gbs, istft_gbs = gbs(prof.get("stft_features")), gbs(prof.get("istft_ola"))
+        step_flops = conv_fl + sum(v["flops"] for k, v in prof.items() if k.startswith("direct_conv"))
         line = {
             "metric": "denoised audio seconds per second (16 kHz), whole job",
             "value": world * audio_s * a.steps / dt,
             "unit": "audio-seconds/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": 1e3 * dt / a.steps,
+            "ms_per_step": ms_step,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32" if a.precision == "f32" else "f16x3 (split hi+lo f16 operands, f32 accumulate)",
             "data": "synthetic",
             "config": {"workload": "%d x %.0f s 16 kHz synthetic mixture(s) per GPU, %s model, STFT+embed+mask+iSTFT end-to-end%s"
                                    % (a.clips_per_gpu, a.seconds, a.kind, " + RCCL all-gather" if world > 1 else ""),
-                       "clips_per_gpu": a.clips_per_gpu, "frames_per_gpu": frames, "weights": "synthetic seed 7",
-                       "parallelism": "clip-sharded x%d" % world},
+                       "clips_per_gpu": a.clips_per_gpu, "distinct_clips_per_gpu": distinct, "frames_per_gpu": frames,
+                       "weights": "synthetic seed 7", "parallelism": "clip-sharded x%d" % world
+                       + (" (ALL RANKS ON ONE DEVICE, gloo: functional check only)" if a.share_device0 else "")},
             "frames_per_s": world * frames * a.steps / dt,
             "x_realtime_per_gpu": audio_s * a.steps / dt,
-            "roofline": {"bound": "mfma", "kernel": kname, "achieved": tflops, "peak": peak,
-                         "unit": "TFLOP/s", "frac": tflops / peak, "traffic": traffic, "traffic_source": traffic_src,
-                         "launches": conv["calls"], "kernel_ms_per_step": conv["ms"] / a.steps,
-                         "executed_tflops": tflops * (3 if a.precision == "f16x3" else 1)},
-            "hbm_kernels": {"stft_features_GBs": gbs(stft), "istft_ola_GBs": gbs(istft), "peak_GBs": HBM_PEAK_GBS},
-            "kernel_ms_per_step": {k: v["ms"] / a.steps for k, v in prof.items()},
+            "status_flags": status,
+            "roofline": {"bound": "mfma", "kernel": "conv_igemm_* (all implicit-GEMM conv launches of a step)",
+                         "achieved": tflops, "peak": peak, "unit": "TFLOP/s", "frac": tflops / peak,
+                         "traffic": traffic, "traffic_source": traffic_src,
+                         "launches": conv_calls, "kernel_ms_per_step": conv_ms,
+                         "avg_launch_ms": conv_ms / conv_calls if conv_calls else None,
+                         "algorithmic_gflop_per_launch": conv_fl / conv_calls / 1e9 if conv_calls else None,
+                         "executed_tflops": tflops * (3 if a.precision == "f16x3" else 1),
+                         "executed_frac": tflops * (3 if a.precision == "f16x3" else 1) / peak,
+                         "source": "hipEvents around every launch in one extra pass after the timed region (%.1f ms wall)"
+                                   % (kpass_ms or 0.0),
+                         # the same algorithmic FLOPs over the UNPROFILED timed step (all kernels, launch gaps): lower bound
+                         "step_level_tflops": step_flops / (ms_step * 1e-3) / 1e12 if step_flops else None,
+                         "per_kernel": {k: {"ms": v["ms"], "launches": v["calls"],
+                                            "tflops": v["flops"] / (v["ms"] * 1e-3) / 1e12 if v["ms"] > 0 else None}
+                                        for k, v in sorted(convs.items())}},
+            "hbm_kernels": {"stft_features_GBs": stft_gbs, "istft_ola_GBs": istft_gbs, "peak_GBs": HBM_PEAK_GBS,
+                            "achievable_GBs": HBM_ACHIEVABLE_GBS,
+                            "stft_frac_of_achievable": stft_gbs / HBM_ACHIEVABLE_GBS if stft_gbs else None,
+                            "istft_frac_of_achievable": istft_gbs / HBM_ACHIEVABLE_GBS if istft_gbs else None,
+                            "bytes_per_frame": 2248},
+            "kernel_ms_per_step": {k: v["ms"] for k, v in sorted(prof.items())},
         }
         if world == 1 and not a.no_cpu_baseline:
-            hip_wav = res["denoised_wav"][:mix_off[1]].cpu().numpy()
-            base, rms = cpu_baseline(W, a.kind, mixes[0], ca[0], cb[0], a.cpu_frames, hip_wav, a.cpu_threads)
-            line["cpu_baseline"] = base
-            line["rms_vs_cpu_f32"] = rms
+            line["cpu_baseline"] = cpu_baseline(W, a.kind, mixes[0], ca[0], cb[0], a.cpu_frames, a.cpu_threads)
+            chk = rms_check(W, a.kind, eng, a.cpu_threads)
+            line["rms_vs_cpu_f32"] = chk["rms"]
+            line["rms_check"] = chk
         print(json.dumps(line), flush=True)
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
     eng.close()
 

@@ -333,18 +333,28 @@ static void launch_t(const ConvArgs& a, hipStream_t s) {
     NHANS_LAUNCH("conv_igemm", (conv_igemm<BN, WM, WN, PREC, ABL>), dim3(grid), dim3(256), lds, s, a);
 }
 
-double launch_conv_igemm(const ConvArgs& a, hipStream_t s) {
+double launch_conv_igemm(const ConvArgs& a, hipStream_t s, const char** kernel) {
     double k = 0;
     for (int i = 0; i < a.nseg; ++i) k += (double)a.seg[i].nchunks * BK;
+    const char* name = "conv_igemm";
+    const bool wide = a.N % 128 == 0;
     if (a.variant >= 1) {
         // (layers marked for grouped summation / split-K always take the LDS-DMA kernel, whatever the
         // launch size: the choice must not depend on the batch)
         if (a.variant == 2 && a.kgroup >= 0 && launch_conv_igemm_halo2d(a, s)) {
-            // 2-D pixel tiles: the 64-channel stride-1 convs
-        } else if (a.variant == 2 && a.kgroup >= 0 && conv_igemm_halo_eligible(a)) launch_conv_igemm_halo(a, s);
-        else launch_conv_igemm_dma(a, s);
+            name = "conv_igemm_halo2d<64>";          // 2-D pixel tiles: the 64-channel stride-1 convs
+        } else if (a.variant == 2 && a.kgroup >= 0 && conv_igemm_halo_eligible(a)) {
+            launch_conv_igemm_halo(a, s);
+            name = wide ? "conv_igemm_halo<128>" : "conv_igemm_halo<64>";
+        } else {
+            launch_conv_igemm_dma(a, s);
+            name = a.kgroup < 0 ? (wide ? "conv_igemm_dma<128,grouped>" : "conv_igemm_dma<64,grouped>")
+                                : (wide ? "conv_igemm_dma<128>" : "conv_igemm_dma<64>");
+        }
+        if (kernel) *kernel = name;
         return 2.0 * (double)a.M * k * (double)a.Nreal;
     }
+    if (kernel) *kernel = wide ? "conv_igemm<128>" : "conv_igemm<64>";
     if (a.prec == 1) {
         if (a.N % 128 == 0) {
 #ifdef NHANS_DEV

@@ -192,12 +192,14 @@ struct Prof {
     }
     Prof(nhans_ctx* c_, hipStream_t s_, const char* name) : c(c_), s(s_) {
         if (!c->profile) return;
-        e = &c->prof[name];
+        if (name) e = &c->prof[name];
         a = take(c);
         b = take(c);
         (void)hipEventRecord(a, s);
     }
-    void done(double flops, double bytes) {
+    void done(double flops, double bytes, const char* late_name = nullptr) {
+        if (!c->profile) return;
+        if (late_name) e = &c->prof[late_name];
         if (!e) return;
         (void)hipEventRecord(b, s);
         e->pending.emplace_back(a, b);
@@ -237,9 +239,11 @@ void set_out_geometry(ConvArgs& a, int B, int Ho, int Wo, int N, int Nreal, int 
 }
 
 void run_conv(nhans_ctx* c, const ConvArgs& a, hipStream_t s) {
-    Prof p(c, s, c->prec ? "conv_igemm_h3" : "conv_igemm_f32");
-    double fl = launch_conv_igemm(a, s);
-    p.done(fl, 0);
+    // profiled under the name of the kernel variant that ran (the variant is chosen per layer)
+    Prof p(c, s, nullptr);
+    const char* name = "conv_igemm";
+    double fl = launch_conv_igemm(a, s, &name);
+    p.done(fl, 0, name);
 }
 
 // ---- embedding tower for `n` context images already in HBM ----------------------------------

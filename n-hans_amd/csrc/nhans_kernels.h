@@ -120,8 +120,8 @@ struct ConvArgs {
     int t2_th, t2_tw, t2_ntr, t2_ntc;
 };
 
-// returns algorithmic FLOPs of the launch (2*M*K*Nreal)
-double launch_conv_igemm(const ConvArgs& a, hipStream_t s);
+// returns algorithmic FLOPs of the launch (2*M*K*Nreal); *kernel (optional) names the variant that ran
+double launch_conv_igemm(const ConvArgs& a, hipStream_t s, const char** kernel = nullptr);
 void launch_conv_igemm_dma(const ConvArgs& a, hipStream_t s);   // conv_igemm_dma.hip
 bool conv_igemm_halo_eligible(const ConvArgs& a);               // conv_igemm_halo.hip
 void launch_conv_igemm_halo(const ConvArgs& a, hipStream_t s);

@@ -57,11 +57,56 @@ def run_case(W, kind, mix, ca, cb, frames, tap_frames):
     return out
 
 
+DEMO_MIXED = REF + "/DEMO_N-HANS/denoising/example2/82057_1_10_652-129742-0017_Silent7_0O-gZoirpRA_30.000_5_8_mixed.wav"
+
+
+def copy_data_fixtures():
+    """Data files of the reference tree that the tests read (inputs / format samples, no source)."""
+    for src, dst in ((SN + "/audio_examples/exp2_noisy.wav", "exp2_noisy.wav"),
+                     # the README's denoising example (README.md:51): its --neg recording and the output
+                     # the reference produced with its trained weights -- the end-to-end golden of
+                     # tests/test_real_weights.py, usable once the LFS weight blob is supplied
+                     (SN + "/audio_examples/exp2_noise.wav", "exp2_noise.wav"),
+                     (SN + "/audio_examples/exp2_denoised.wav", "exp2_denoised.wav"),
+                     (SN + "/trained_model/81448_0-1000000.index", "denoiser.index"),
+                     (SS + "/trained_model/81457_2-545000.index", "separator.index"),
+                     # a TensorFlow-written waveform: `*_mixed.wav` of the demo material is
+                     # inverse_stft(stft(x)) dumped by SN/main.py:296-306 (22,480 float32 samples)
+                     (DEMO_MIXED, "demo_tf_istft_mixed.wav")):
+        shutil.copyfile(src, os.path.join(OUT, dst))
+        os.chmod(os.path.join(OUT, dst), 0o644)
+
+
+def new_cases_r2():
+    """Cases added in round 2 (kept separate so they can be regenerated without the long exp2 run)."""
+    Wd = weights.synthetic_weights("denoiser", 7)
+    Ws = weights.synthetic_weights("separator", 7)
+    print("case separator10s (separator, 10 s clip, 12 frames)", flush=True)
+    mix = O.trim_to_frames(O.normalise(synth.mixture(5, 10.0)))
+    fr = [0, 1, 16, 17, 18, 250, 499, 700, 979, 980, 996, 997]
+    res = run_case(Ws, "separator", mix, O.normalise(synth.speaker_context(5, low=True)),
+                   O.normalise(synth.speaker_context(5, low=False)), fr, None)
+    np.savez_compressed(OUT + "/case_separator10s.npz", **res)
+
+    print("case postproc (denoiser, 0.6 s clip, all frames: removed / snr_est / compensated)", flush=True)
+    mix = O.trim_to_frames(O.normalise(synth.mixture(40, 0.6)))
+    ca, cb = O.normalise(synth.silent()), O.normalise(synth.noise_context(40))
+    out = {}
+    for tag, kw in (("fixed", dict(compensate=0.3, ac=False)), ("ac", dict(compensate=0.0, ac=True))):
+        r = O.enhance(mix, ca, cb, Wd, "denoiser", batch=8, **kw)
+        for k in ("denoised_wav", "mixed_wav", "removed_wav", "compensated_wav"):
+            out["%s_%s" % (k, tag)] = f32(r[k])
+        out["snr_est_%s" % tag] = np.float64(r["snr_est"])
+    np.savez_compressed(OUT + "/case_postproc.npz", **out)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     # ---- data fixtures from the reference tree
-    shutil.copyfile(SN + "/audio_examples/exp2_noisy.wav", OUT + "/exp2_noisy.wav")
-    os.chmod(OUT + "/exp2_noisy.wav", 0o644)
+    copy_data_fixtures()
+    if len(sys.argv) > 1 and sys.argv[1] == "r2":
+        new_cases_r2()
+        return
     geo = {"cases": [], "examples": {}}
     for n in (49600, 63520, 160000, 400, 559, 560, 399, 32240):
         kept, t = spec.frames_for_samples(n)
@@ -110,6 +155,7 @@ def main():
             allres["%s_%d" % (k, i)] = r[k]
     allres["lens"] = np.asarray(lens, dtype=np.int64)
     np.savez_compressed(OUT + "/case_ragged.npz", **allres)
+    new_cases_r2()
     print("golden vectors written to", OUT)
 
 

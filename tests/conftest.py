@@ -10,13 +10,26 @@ if ROOT not in sys.path:
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 
+def _gpu_present():
+    # device_count() does not initialise the HIP runtime on this image (is_available() does); the
+    # multi-process tests rely on this process not having touched the GPU when it starts helpers
+    import torch
+    return torch.cuda.device_count() > 0
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # Worker processes of the multi-process tests are forked from a fork server that is started
+    # HERE, before anything in this process can have initialised the GPU: a process that has must
+    # never exec another program on the GPU pool, and a fork server never execs for its children.
+    import multiprocessing as mp
+    from multiprocessing import forkserver
+    mp.set_forkserver_preload(["numpy"])
+    forkserver.ensure_running()
 
 
 def pytest_collection_modifyitems(config, items):
-    import torch
-    if torch.cuda.is_available():
+    if _gpu_present():
         return
     skip = pytest.mark.skip(reason="no HIP device")
     for item in items:

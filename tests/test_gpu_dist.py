@@ -1,0 +1,203 @@
+"""Multi-process runs of the REAL engine on the GPU box: two ranks, each with its own
+libnhans_hip context, clips sharded by dist.shard_bounds, outputs reassembled by the path's one
+all-gather -- and the result compared bit for bit with the single-process batch.
+
+The driver's GPU box has one MI355X, so the two ranks share device 0 and the collective runs over
+gloo (host); the RCCL variant of the same worker needs two devices and is skipped otherwise.  SCALE
+numbers on 8 GPUs are the driver's to measure.
+
+Workers are forked from the fork server started in conftest.py (never an exec from a process that
+has initialised the GPU).
+"""
+import multiprocessing as mp
+import os
+import socket
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+N_CLIPS = 5
+SECS = [0.3, 1.0, 0.025, 0.7, 0.45]
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _batch():
+    import nhans_amd  # noqa: F401
+    from nhans_amd import apply, synth
+    mixes = [apply.trim_to_frames(apply.normalise(synth.mixture(300 + i, SECS[i]))) for i in range(N_CLIPS)]
+    ca = [apply.normalise(synth.silent()) for _ in range(N_CLIPS)]
+    cb = [apply.normalise(synth.noise_context(300 + i)) for i in range(N_CLIPS)]
+    return mixes, ca, cb
+
+
+def _rank_main(rank, world, port, backend, q):
+    """One rank: real Engine, dist.enhance_sharded, report every gathered waveform."""
+    try:
+        import sys
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        sys.path.insert(0, root)
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                          HSA_ENABLE_IPC_MODE_LEGACY="0")
+        import torch
+        import torch.distributed as tdist
+        import nhans_amd  # noqa: F401
+        from nhans_amd import dist as nd, engine, weights
+        dev_index = rank if backend == "nccl" else 0
+        torch.cuda.set_device(dev_index)
+        if backend == "nccl":
+            tdist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev_index))
+            gdev = torch.device("cuda", dev_index)
+        else:
+            tdist.init_process_group("gloo", rank=rank, world_size=world)
+            gdev = torch.device("cpu")
+        eng = engine.Engine("denoiser", weights.synthetic_weights("denoiser", 7), device=dev_index, precision="f16x3")
+        mixes, ca, cb = _batch()
+        seen = []
+
+        def run(m, a, b):
+            seen.append(len(m))
+            res = eng.enhance(m, a, b, want_mixed=False)
+            return [torch.from_numpy(w).to(gdev) for w in res["denoised_wav"]]
+        out = nd.enhance_sharded(run, mixes, ca, cb, gdev)
+        lo, hi = nd.shard_bounds(len(mixes), world, rank)
+        q.put((rank, seen == [hi - lo], [w.cpu().numpy() for w in out]))
+        tdist.barrier()
+        tdist.destroy_process_group()
+        eng.close()
+    except Exception as e:      # surface the failure instead of a timeout
+        import traceback
+        q.put((rank, False, traceback.format_exc() + repr(e)))
+
+
+def _run_two_ranks(backend):
+    ctx = mp.get_context("forkserver")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_rank_main, args=(r, 2, port, backend, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    try:
+        res = sorted((q.get(timeout=600) for _ in procs), key=lambda t: t[0])
+    finally:
+        for p in procs:
+            p.join(timeout=120)
+            if p.is_alive():
+                p.kill()
+    return res
+
+
+def _single_process_reference():
+    import nhans_amd  # noqa: F401
+    from nhans_amd import engine, weights
+    eng = engine.Engine("denoiser", weights.synthetic_weights("denoiser", 7), precision="f16x3")
+    mixes, ca, cb = _batch()
+    ref = eng.enhance(mixes, ca, cb, want_mixed=False)["denoised_wav"]
+    eng.close()
+    return ref
+
+
+def _check(res, ref):
+    for rank, own_shard_only, waves in res:
+        assert own_shard_only is True, waves                       # each rank ran exactly its block of clips
+        assert len(waves) == N_CLIPS
+        for i in range(N_CLIPS):                                   # every rank holds the whole batch, bit-equal
+            assert np.array_equal(waves[i], ref[i]), (rank, i)
+
+
+def test_two_ranks_one_gpu_gloo_equals_single_process(lib_built):
+    res = _run_two_ranks("gloo")              # workers first: this process has not touched the GPU yet
+    _check(res, _single_process_reference())
+
+
+def test_two_ranks_two_gpus_rccl_equals_single_process(lib_built):
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs (RCCL refuses two ranks on one device)")
+    res = _run_two_ranks("nccl")
+    _check(res, _single_process_reference())
+
+
+def _cli_rank(rank, world, port, argv, q):
+    try:
+        import sys
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        sys.path.insert(0, root)
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                          LOCAL_RANK="0", NHANS_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+        import nhans_amd  # noqa: F401
+        from nhans_amd import apply
+        apply.main(argv)
+        import torch.distributed as tdist
+        tdist.barrier()
+        tdist.destroy_process_group()
+        q.put((rank, True, ""))
+    except Exception as e:
+        import traceback
+        q.put((rank, False, traceback.format_exc() + repr(e)))
+
+
+def test_cli_directory_mode_sharded_over_two_ranks(lib_built, tmp_path):
+    """`nhans_denoiser --input <dir> ...` under WORLD_SIZE=2 (what torch.distributed.run sets): the
+    directory is one batch, sharded over the ranks, rank 0 writes every file; same bytes as one rank."""
+    from scipy.io import wavfile
+    import nhans_amd  # noqa: F401
+    from nhans_amd import synth
+    ind, negd = tmp_path / "in", tmp_path / "neg"
+    ind.mkdir()
+    negd.mkdir()
+    names = ["clip%02d.wav" % i for i in range(N_CLIPS)]
+    for i, n in enumerate(names):
+        wavfile.write(str(ind / n), 16000, synth.mixture(300 + i, SECS[i]))
+        wavfile.write(str(negd / n), 16000, synth.noise_context(300 + i))
+    common = ["--input", str(ind), "--neg", str(negd), "--pos", str(tmp_path / "Silent.wav"), "--weights", "synthetic"]
+    ctx = mp.get_context("forkserver")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_cli_rank, args=(r, 2, port, common + ["--output", str(tmp_path / "out2")], q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    try:
+        res = sorted(q.get(timeout=600) for _ in procs)
+    finally:
+        for p in procs:
+            p.join(timeout=120)
+            if p.is_alive():
+                p.kill()
+    assert [r[:2] for r in res] == [(0, True), (1, True)], res
+    # one rank, same CLI
+    p1 = ctx.Process(target=_cli_single, args=(common + ["--output", str(tmp_path / "out1")], q))
+    p1.start()
+    ok = q.get(timeout=600)
+    p1.join(timeout=120)
+    assert ok == "done", ok
+    files = sorted(os.listdir(str(tmp_path / "out1")))
+    assert files == sorted(os.listdir(str(tmp_path / "out2"))) and len(files) == 4 * N_CLIPS
+    for f in files:
+        a = open(str(tmp_path / "out1" / f), "rb").read()
+        b = open(str(tmp_path / "out2" / f), "rb").read()
+        assert a == b, f
+
+
+def _cli_single(argv, q):
+    try:
+        import sys
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        sys.path.insert(0, root)
+        for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+            os.environ.pop(k, None)
+        import nhans_amd  # noqa: F401
+        from nhans_amd import apply
+        apply.main(argv)
+        q.put("done")
+    except Exception as e:
+        import traceback
+        q.put(traceback.format_exc() + repr(e))

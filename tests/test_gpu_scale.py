@@ -1,0 +1,260 @@
+"""GPU tests at BASELINE configuration scale (configs[2]: hundreds of clips, hundreds of
+1024-frame chunks, clips straddling chunk boundaries) and of the post-outputs / separator at 10 s.
+Oracle runs of that size are out of reach, so the checks are: committed golden frames of a clip placed
+at several batch positions, bitwise equality with the single-clip run (batch, chunk and position
+invariance), finiteness of every output, and the STFT->iSTFT identity on sampled clips.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import nhans_amd  # noqa: F401
+from nhans_amd import apply, engine, hip, spec, synth
+from oracle import nhans_oracle as O
+from conftest import GOLDEN, load_case
+
+pytestmark = pytest.mark.gpu
+
+LOGIT_TOL = 1e-4
+WAV_RMS_TOL = 1e-3
+
+
+@pytest.fixture(scope="module")
+def eng(lib_built, weights_denoiser):
+    e = engine.Engine("denoiser", weights_denoiser, precision="f16x3")
+    yield e
+    e.close()
+
+
+@pytest.fixture(scope="module")
+def eng_sep(lib_built, weights_separator):
+    e = engine.Engine("separator", weights_separator, precision="f16x3")
+    yield e
+    e.close()
+
+
+def _clip(cid, seconds):
+    return (apply.trim_to_frames(apply.normalise(synth.mixture(cid, seconds))),
+            apply.normalise(synth.silent()), apply.normalise(synth.noise_context(cid)))
+
+
+def _golden_10s():
+    return _clip(0, 10.0)         # the clip of tests/golden/case_synth10s.npz (oracle/make_golden.py)
+
+
+@pytest.mark.parametrize("prec", ["f32", "f16x3"])
+def test_ragged_batch_of_64_clips_across_chunk_boundaries(eng, prec):
+    """64 clips of 1..998 frames in one nhans_enhance_clips call with a chunk size (1000) that no
+    clip length divides: most clips straddle a chunk boundary.  The golden 10 s clip sits at batch
+    positions 0, 31 and 63."""
+    eng.set_precision(prec)
+    g = load_case("case_synth10s")
+    secs = [0.025, 0.035, 0.31, 0.77, 1.0, 1.5, 2.25, 0.5]
+    clips = []
+    for i in range(64):
+        clips.append(_golden_10s() if i in (0, 31, 63) else _clip(100 + i, secs[i % len(secs)]))
+    mixes, cas, cbs = [list(x) for x in zip(*clips)]
+    nfr = [spec.frames_for_samples(len(m))[1] for m in mixes]
+    foff = np.concatenate([[0], np.cumsum(nfr)])
+    eng.set_option("frames_per_chunk", 1000)
+    try:
+        out = eng.enhance(mixes, cas, cbs, want_mixed=True, taps=True)
+        assert eng.take_status() == 0
+        assert out["logits"].shape == (foff[-1], 201) and foff[-1] > 5000
+        assert np.isfinite(out["logits"]).all()
+        for w in out["denoised_wav"]:
+            assert np.isfinite(w).all()
+        for pos in (0, 31, 63):
+            lg = out["logits"][foff[pos]:foff[pos + 1]]
+            assert np.abs(lg[g["frames"]] - g["logits"]).max() < 5 * LOGIT_TOL, pos   # kernel's own features
+            assert np.array_equal(lg, out["logits"][foff[0]:foff[1]])                   # position-invariant, bit for bit
+            assert np.array_equal(out["denoised_wav"][pos], out["denoised_wav"][0])
+        # sampled clips: the batch run == the clip on its own (other chunking too), bit for bit
+        eng.set_option("frames_per_chunk", 1024)
+        for i in (0, 1, 2, 17, 30, 32, 62):
+            single = eng.enhance([mixes[i]], [cas[i]], [cbs[i]], want_mixed=True, taps=True)
+            assert np.array_equal(single["logits"], out["logits"][foff[i]:foff[i + 1]]), i
+            assert np.array_equal(single["denoised_wav"][0], out["denoised_wav"][i]), i
+            assert np.array_equal(single["mixed_wav"][0], out["mixed_wav"][i]), i
+    finally:
+        eng.set_option("frames_per_chunk", 1024)
+
+
+def test_batch_of_256_ten_second_clips(eng):
+    """BASELINE configs[2] in one call: 256 x 10 s = 255,488 frame windows, 250 chunks of 1024.  32
+    distinct clips repeated 8 times, the golden clip among them: golden frames at three batch
+    positions, every repetition bit-identical to the first, every sample finite, round trip intact."""
+    eng.set_precision("f16x3")
+    g = load_case("case_synth10s")
+    distinct = [_golden_10s()] + [_clip(200 + i, 10.0) for i in range(1, 32)]
+    clips = [distinct[i % 32] for i in range(256)]
+    mixes, cas, cbs = [list(x) for x in zip(*clips)]
+    mix_t, mix_off = eng._dev(mixes)
+    ca_t, ca_off = eng._dev(cas)
+    cb_t, cb_off = eng._dev(cbs)
+    res = eng.enhance_device(mix_t, mix_off, ca_t, ca_off, cb_t, cb_off, want_mixed=True, taps=True)
+    assert eng.take_status() == 0                                  # no f16 saturation anywhere
+    lg = res["logits"].view(256, 998, 201)
+    den = res["denoised_wav"].view(256, 159920)
+    assert bool(torch.isfinite(lg).all()) and bool(torch.isfinite(den).all())
+    gl = torch.from_numpy(g["logits"]).to(lg.device)
+    fr = torch.from_numpy(g["frames"].astype(np.int64)).to(lg.device)
+    for pos in (0, 96, 224):                                       # golden clip = every 32nd
+        assert float((lg[pos][fr] - gl).abs().max()) < 5 * LOGIT_TOL, pos
+    first = lg[:32]
+    for rep in range(1, 8):                                        # chunk phase differs per repetition: 998*32 % 1024 != 0
+        assert torch.equal(lg[32 * rep:32 * rep + 32], first), rep
+        assert torch.equal(den[32 * rep:32 * rep + 32], den[:32]), rep
+    # single-clip run of three of them == their rows in the batch
+    for i in (0, 13, 31):
+        single = eng.enhance([mixes[i]], [cas[i]], [cbs[i]], want_mixed=False, taps=True)
+        assert np.array_equal(single["logits"], lg[i].cpu().numpy()), i
+        assert np.array_equal(single["denoised_wav"][0], den[i].cpu().numpy()), i
+    # iSTFT(STFT(x)) == x in the interior, for a sample of clips
+    rt = res["mixed_wav"].view(256, 159920)
+    for i in (5, 77, 255):
+        x = torch.from_numpy(mixes[i]).to(rt.device)
+        assert float((rt[i][240:-240] - x[240:-240]).abs().max()) < 2e-4
+
+
+@pytest.mark.parametrize("prec", ["f32", "f16x3"])
+def test_separator_ten_second_clip(eng_sep, prec):
+    eng_sep.set_precision(prec)
+    g = load_case("case_separator10s")
+    mix = apply.trim_to_frames(apply.normalise(synth.mixture(5, 10.0)))
+    ca = apply.normalise(synth.speaker_context(5, low=True))          # interferer (--neg) -> noise context
+    cb = apply.normalise(synth.speaker_context(5, low=False))         # target (--pos) -> clean context
+    out = eng_sep.enhance([mix], [ca], [cb], want_mixed=False, taps=True)
+    assert out["logits"].shape == (998, 201)
+    assert np.abs(out["emb"][0] - g["emb_a"]).max() < 1e-4 and np.abs(out["emb"][1] - g["emb_b"]).max() < 1e-4
+    assert np.abs(out["logits"][g["frames"]] - g["logits"]).max() < 5 * LOGIT_TOL
+    # identical features in: the strict logit bar
+    lm = torch.from_numpy(g["logmag"]).cuda()
+    lg, _ = eng_sep.mask_net(lm, [0, 998], torch.from_numpy(g["emb_a"][None]).cuda(), torch.from_numpy(g["emb_b"][None]).cuda())
+    assert np.abs(lg.cpu().numpy()[g["frames"]] - g["logits"]).max() < LOGIT_TOL
+    # a batch of 4 of them, chunked mid-clip == the single run
+    eng_sep.set_option("frames_per_chunk", 700)
+    try:
+        b = eng_sep.enhance([mix] * 4, [ca] * 4, [cb] * 4, want_mixed=False, taps=True)
+    finally:
+        eng_sep.set_option("frames_per_chunk", 1024)
+    for i in range(4):
+        assert np.array_equal(b["logits"][998 * i:998 * (i + 1)], out["logits"])
+        assert np.array_equal(b["denoised_wav"][i], out["denoised_wav"][0])
+
+
+@pytest.mark.parametrize("mode", ["fixed", "ac"])
+def test_post_outputs_removed_snr_compensated(eng, mode, tmp_path, capsys):
+    """SN/apply.py:456-472 through apply_snc: removed = mixed_processed - denoised, snr_est, and
+    compensated with --compensate 0.3 / --ac, against the oracle's restatement."""
+    from scipy.io import wavfile
+    eng.set_precision("f16x3")
+    apply.set_engine("denoiser", eng)
+    g = load_case("case_postproc")
+    mixp, negp = str(tmp_path / "in.wav"), str(tmp_path / "neg.wav")
+    wavfile.write(mixp, 16000, synth.mixture(40, 0.6))
+    wavfile.write(negp, 16000, synth.noise_context(40))
+    out = str(tmp_path / "clip_denoised.wav")
+    apply.FLAGS.ac, apply.FLAGS.compensate = (mode == "ac"), (0.0 if mode == "ac" else 0.3)
+    try:
+        apply.apply_snc(mixp, str(tmp_path / "Silent.wav"), negp, out)        # absent Silent.wav -> zeros
+    finally:
+        apply.FLAGS.ac, apply.FLAGS.compensate = False, 0.0
+    printed = float(capsys.readouterr().out.split()[0])
+    assert abs(printed / float(g["snr_est_" + mode]) - 1) < 1e-3
+    for name, key in (("clip_denoised.wav", "denoised_wav"), ("clip_mixed_processed.wav", "mixed_wav"),
+                      ("clip_removed.wav", "removed_wav"), ("clip_compensated.wav", "compensated_wav")):
+        r, w = wavfile.read(str(tmp_path / name))
+        ref = g["%s_%s" % (key, mode)]
+        assert r == 16000 and w.dtype == np.float32 and w.shape == ref.shape
+        assert np.sqrt(np.mean((w - ref) ** 2)) < WAV_RMS_TOL, name
+        assert np.abs(w - ref).max() < 2e-3, name
+    _, den = wavfile.read(out)
+    _, comp = wavfile.read(str(tmp_path / "clip_compensated.wav"))
+    assert not np.array_equal(den, comp)                                       # the factor really is non-zero
+
+
+def test_tf_written_waveform_round_trips(eng):
+    """`*_mixed.wav` of the reference's demo material is inverse_stft(stft(x)) written by TensorFlow
+    (SN/main.py:296-306).  In the interior of such a signal STFT -> iSTFT is the identity, so the
+    HIP pair must give the TF-written samples back."""
+    from scipy.io import wavfile
+    r, y = wavfile.read(os.path.join(GOLDEN, "demo_tf_istft_mixed.wav"))
+    assert r == 16000 and y.dtype == np.float32 and (len(y) - 400) % 160 == 0
+    t = torch.from_numpy(y).cuda()
+    lm, ph = eng.stft_features(t, [0, len(y)])
+    w, _ = eng.istft(lm, ph, [0, lm.shape[0]])
+    w = w.cpu().numpy()
+    assert w.shape == y.shape
+    assert np.abs(w[240:-240] - y[240:-240]).max() < 2e-4 * max(1.0, np.abs(y).max())
+    # and against the oracle on the whole signal, edges included
+    ref = O.recover_samples(*O.logmag_phase(O.stft(y)))
+    assert np.sqrt(np.mean((w - ref) ** 2)) < 1e-5
+
+
+def test_directory_mode_is_one_batch_with_distinct_side_files(eng, tmp_path):
+    """README.md:59-66: --input/--output/--neg directories paired by file name.  All clips go through
+    ONE ragged call; side files are per clip (the reference's save_to[:-12] cut would collide)."""
+    from scipy.io import wavfile
+    eng.set_precision("f16x3")
+    apply.set_engine("denoiser", eng)
+    ind, negd, outd = tmp_path / "in", tmp_path / "neg", tmp_path / "out"
+    ind.mkdir(); negd.mkdir()
+    names = ["a.wav", "bb.wav", "recording_0001.wav", "recording_0002.wav"]
+    for i, n in enumerate(names):
+        wavfile.write(str(ind / n), 16000, synth.mixture(60 + i, 0.3 + 0.2 * i))
+        wavfile.write(str(negd / n), 16000, synth.noise_context(60 + i))
+    calls = []
+    orig = eng.enhance
+    eng.enhance = lambda *a, **k: (calls.append(len(a[0])), orig(*a, **k))[1]
+    try:
+        apply.main(["--input", str(ind), "--neg", str(negd), "--pos", str(tmp_path / "Silent.wav"),
+                    "--output", str(outd), "--weights", "synthetic"])
+    finally:
+        del eng.enhance
+    assert calls == [4]                                                        # one batch
+    got = sorted(os.listdir(str(outd)))
+    want = sorted(n for s in names for n in (s, s[:-4] + "_mixed_processed.wav", s[:-4] + "_removed.wav",
+                                             s[:-4] + "_compensated.wav"))
+    assert got == want
+    for i, n in enumerate(names):                                              # == the file-mode result
+        single = str(tmp_path / ("single%d_denoised.wav" % i))
+        apply.apply_snc(str(ind / n), str(tmp_path / "Silent.wav"), str(negd / n), single)
+        assert np.array_equal(wavfile.read(single)[1], wavfile.read(str(outd / n))[1])
+
+
+def test_launch_failure_reaches_the_caller(lib_built):
+    """A launch the runtime rejects must come back as NHANS_EHIP, not as NHANS_OK + garbage."""
+    lib = hip.load()
+    assert lib.nhans_debug_launch_probe(1024, None) == 0
+    assert lib.nhans_debug_launch_probe(150 * 1024, None) == 0                # within the 160 KB of a gfx950 CU
+    torch.cuda.synchronize()
+    rc = lib.nhans_debug_launch_probe(1 << 20, None)                           # 1 MB of LDS does not exist
+    assert rc == -2 and b"launch_probe" in lib.nhans_last_error()
+    assert lib.nhans_debug_launch_probe(1024, None) == 0                       # the error does not stick
+    torch.cuda.synchronize()
+
+
+def test_saturation_is_detected_and_rerun_in_f32(lib_built, weights_denoiser):
+    """f16x3 carries activations as hi+lo f16: |v| >= 65504 cannot be represented.  Weights scaled so
+    that block 1 overflows must raise the status flag, and Engine.enhance must hand back the f32
+    matrix-core result instead of clamped values."""
+    W = dict(weights_denoiser)
+    W["resblock1_1_conv1/w"] = (W["resblock1_1_conv1/w"] * np.float32(3.0e5)).astype(np.float32)
+    mix, ca, cb = _clip(7, 0.3)
+    e32 = engine.Engine("denoiser", W, precision="f32")
+    ref = e32.enhance([mix], [ca], [cb], want_mixed=False, taps=True)
+    assert e32.take_status() == 0
+    e32.close()
+    e16 = engine.Engine("denoiser", W, precision="f16x3")
+    mix_t, mix_off = e16._dev([mix]); ca_t, ca_off = e16._dev([ca]); cb_t, cb_off = e16._dev([cb])
+    e16.enhance_device(mix_t, mix_off, ca_t, ca_off, cb_t, cb_off)
+    assert e16.take_status() & hip.STATUS_SATURATED
+    assert e16.take_status() == 0                                              # read-and-clear
+    with pytest.warns(UserWarning, match="f16 range"):
+        got = e16.enhance([mix], [ca], [cb], want_mixed=False, taps=True)
+    assert e16.precision == "f16x3"
+    assert np.array_equal(got["logits"], ref["logits"])
+    e16.close()

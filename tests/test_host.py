@@ -176,6 +176,52 @@ def test_cli_flag_surface():
     apply.FLAGS.ac, apply.FLAGS.compensate = False, 0.0
 
 
+def test_side_file_names():
+    """SN/apply.py:457-470 cuts 12 characters off the output path; kept where that is meaningful."""
+    assert apply.side_prefix("./audio_examples/denoised.wav") == "./audio_examples/"           # the reference's default
+    assert apply.side_prefix("out/exp2_denoised.wav") == "out/exp2_"
+    assert apply.side_prefix("out/a.wav") == "out/a_"                                            # not 'out/a.wav'[:-12] == ''
+    assert apply.side_prefix("out/recording_0001.wav") != apply.side_prefix("out/recording_0002.wav")
+
+
+def test_directory_mode_batches_and_names_side_files(tmp_path, monkeypatch):
+    """Directory mode without a GPU: a stand-in engine records that all clips arrive in ONE call and
+    returns recognisable waveforms; the files written must be per clip."""
+    from scipy.io import wavfile as wf
+
+    class FakeEngine:
+        calls = []
+
+        def enhance(self, mixes, ca, cb, want_mixed=True, taps=False):
+            FakeEngine.calls.append(len(mixes))
+            return {"denoised_wav": [m * np.float32(0.5) for m in mixes], "mixed_wav": [m.copy() for m in mixes]}
+
+    ind, negd, outd = tmp_path / "in", tmp_path / "neg", tmp_path / "out"
+    ind.mkdir()
+    negd.mkdir()
+    names = ["a.wav", "bb.wav", "recording_0001.wav", "recording_0002.wav"]
+    for i, n in enumerate(names):
+        wf.write(str(ind / n), 16000, synth.mixture(60 + i, 0.1 + 0.05 * i))
+        wf.write(str(negd / n), 16000, synth.noise_context(60 + i, 1.0))
+    wf.write(str(ind / "tiny.wav"), 16000, np.ones(300, dtype=np.int16))       # < one window: reported and skipped
+    wf.write(str(negd / "tiny.wav"), 16000, synth.noise_context(1, 1.0))
+    (ind / "notes.txt").write_text("not audio")
+    monkeypatch.setitem(apply._engines, "denoiser", FakeEngine())
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    apply.main(["--input", str(ind), "--neg", str(negd), "--pos", str(tmp_path / "Silent.wav"), "--output", str(outd),
+                "--weights", "synthetic", "--compensate", "0.25"])
+    apply.FLAGS.compensate = 0.0
+    assert FakeEngine.calls == [4]
+    want = sorted(n for s in names for n in (s, s[:-4] + "_mixed_processed.wav", s[:-4] + "_removed.wav",
+                                             s[:-4] + "_compensated.wav"))
+    assert sorted(os.listdir(str(outd))) == want
+    for i, n in enumerate(names):
+        x = apply.trim_to_frames(apply.normalise(synth.mixture(60 + i, 0.1 + 0.05 * i)))
+        assert np.array_equal(wf.read(str(outd / n))[1], x * np.float32(0.5))
+        # compensated = denoised + (mixed - denoised) * 0.25
+        assert np.allclose(wf.read(str(outd / (n[:-4] + "_compensated.wav")))[1], x * 0.5 + (x - x * 0.5) * 0.25, atol=1e-7)
+
+
 def test_missing_checkpoint_fails_loudly(tmp_path, monkeypatch):
     monkeypatch.setattr(apply.FLAGS, "weights", "checkpoint")
     monkeypatch.setattr(apply.FLAGS, "model_dir", str(tmp_path))
@@ -198,6 +244,20 @@ def test_library_exports_every_declared_symbol(lib_built):
     out = ctypes.c_void_p()
     assert h.nhans_create(0, bad, 64, 0, ctypes.byref(out)) == -1            # NHANS_EINVAL: bad magic
     assert b"magic" in h.nhans_last_error()
+
+
+def test_launch_failure_returns_negative_code(lib_built):
+    """The launch-error channel end to end: a kernel launch that cannot happen (here: no device at
+    all on the CPU box; on the GPU box tests/test_gpu_scale.py asks for 1 MB of LDS) must come back
+    as a negative code with the kernel's name, never as NHANS_OK."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present: covered by tests/test_gpu_scale.py::test_launch_failure_reaches_the_caller")
+    h = hip.load()
+    rc = h.nhans_debug_launch_probe(1 << 20, None)
+    assert rc == -2 and b"launch_probe" in h.nhans_last_error()
+    flags = ctypes.c_int(0)
+    assert h.nhans_take_status(None, ctypes.byref(flags), None) == -1          # null context: EINVAL, not a crash
 
 
 def test_no_cpu_fallback_without_gpu():

@@ -149,3 +149,18 @@ def test_golden_vectors_reproduce(weights_denoiser, weights_separator):
                   weights_separator, "separator", frames=[99])
     i = list(s["frames"]).index(99)
     assert np.abs(r["logits"][99] - s["logits"][i]).max() < 1e-5
+
+
+def test_oracle_round_trips_a_tensorflow_written_waveform():
+    """tests/golden/demo_tf_istft_mixed.wav is inverse_stft(stft(x)) written by TensorFlow
+    (SN/main.py:296-306 dump of the demo material).  A signal of that form is a fixed point of
+    STFT -> iSTFT in its interior (full overlap), so the oracle pair must return TF's own samples."""
+    from scipy.io import wavfile
+    r, y = wavfile.read(os.path.join(GOLDEN, "demo_tf_istft_mixed.wav"))
+    assert r == 16000 and y.dtype == np.float32 and len(y) == 22480 and (len(y) - 400) % 160 == 0
+    z = O.recover_samples(*O.logmag_phase(O.stft(y)))
+    assert z.shape == y.shape
+    # the 1e-5 magnitude floor of log(|X| + 1e-5) is the only thing that is not exactly inverted
+    assert np.abs(z[240:-240] - y[240:-240]).max() < 5e-5
+    # TF's synthesis window leaves the partially covered edges attenuated: a second pass attenuates again
+    assert np.abs(z[:100]).sum() < np.abs(y[:100]).sum() or np.abs(y[:100]).sum() == 0
