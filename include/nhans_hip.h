@@ -85,7 +85,8 @@ void nhans_destroy(nhans_ctx* ctx);
  *           FP32-class accuracy, activations must stay below the f16 range 65504),
  *          "conv_variant" (-1: automatic, default; 0: register-staged 128-pixel kernel; 1: LDS-DMA
  *           256-pixel kernel; 2: halo-reuse kernel with producer/consumer waves where the conv
- *           allows it, else 1 -- same results within rounding, different speed).
+ *           allows it (512-pixel tiles for the 64-channel convs), else 1; 3: as 2 with the
+ *           64-channel convs on 2-D 256-pixel tiles -- same results within rounding, different speed).
  * (A `make DEV=1` build adds "debug_cycles_ptr" and the NHANS_ABLATE / NHANS_HALO2D environment
  * switches used by tools/; the default build has no developer hooks and reads no environment.)
  * Besides the workspace a context holds 64 MB of split-K scratch for the few launches that are

@@ -333,7 +333,9 @@ static void launch_t(const ConvArgs& a, hipStream_t s) {
     NHANS_LAUNCH("conv_igemm", (conv_igemm<BN, WM, WN, PREC, ABL>), dim3(grid), dim3(256), lds, s, a);
 }
 
-double launch_conv_igemm(const ConvArgs& a, hipStream_t s, const char** kernel) {
+double launch_conv_igemm(const ConvArgs& a0, hipStream_t s, const char** kernel) {
+    ConvArgs a = a0;
+    a.halo64_tile512 = a.variant == 2;
     double k = 0;
     for (int i = 0; i < a.nseg; ++i) k += (double)a.seg[i].nchunks * BK;
     const char* name = "conv_igemm";
@@ -341,9 +343,13 @@ double launch_conv_igemm(const ConvArgs& a, hipStream_t s, const char** kernel) 
     if (a.variant >= 1) {
         // (layers marked for grouped summation / split-K always take the LDS-DMA kernel, whatever the
         // launch size: the choice must not depend on the batch)
-        if (a.variant == 2 && a.kgroup >= 0 && launch_conv_igemm_halo2d(a, s)) {
-            name = "conv_igemm_halo2d<64>";          // 2-D pixel tiles: the 64-channel stride-1 convs
-        } else if (a.variant == 2 && a.kgroup >= 0 && conv_igemm_halo_eligible(a)) {
+        const bool halo_ok = a.variant >= 2 && a.kgroup >= 0;
+        if (halo_ok && !wide && a.variant == 2 && conv_igemm_halo_eligible(a)) {
+            launch_conv_igemm_halo(a, s);            // the 64-channel stride-1 convs: 512-pixel tiles
+            name = "conv_igemm_halo<64,512>";
+        } else if (halo_ok && launch_conv_igemm_halo2d(a, s)) {
+            name = "conv_igemm_halo2d<64>";          // (variant 3) 2-D 256-pixel tiles for the same layers
+        } else if (halo_ok && (a.halo64_tile512 = 0, conv_igemm_halo_eligible(a))) {
             launch_conv_igemm_halo(a, s);
             name = wide ? "conv_igemm_halo<128>" : "conv_igemm_halo<64>";
         } else {

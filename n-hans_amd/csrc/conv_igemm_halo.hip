@@ -39,22 +39,39 @@
 namespace nhans {
 
 namespace {
-constexpr int HBM = 256;      // output pixels per workgroup
-constexpr int HR = 320;       // rows of one halo image
-constexpr int BST = 4;        // weight ring stages
 constexpr int NCW = 8;        // consumer (MFMA) waves
 constexpr int NPW = 4;        // producer (DMA) waves
-constexpr int NAP = HR * 8 / (NPW * 64);   // activation DMA instructions per producer thread per image (10)
+
+// Tile shapes.  The work of a consumer wave is always 64 pixels x 64 channels (TM = TN = 2: 8 operand
+// reads feed 12 MFMAs per k-step) except in the 256 x 64 shape:
+//   HBM 256, BN 128: wave grid 4 x 2, halo image 320 rows, 4 weight stages (80 + 64 KB)   N >= 128
+//   HBM 512, BN  64: wave grid 8 x 1, halo image 544 rows, 3 weight stages (136 + 24 KB = all 160 KB
+//                    of the CU)                                                           N = 64
+//   HBM 256, BN  64: wave grid 4 x 2, wave tile 64 x 32 (6 reads per 6 MFMAs)             kept for A/B
+// The 512-pixel shape exists because the 64-channel convs (K = 1024: 32 taps) are the ones where the
+// per-tile fixed costs -- first halo image, epilogue round trips -- weigh most and where a 64 x 32
+// wave tile makes the LDS operand reads a co-bottleneck (profiles/r01).
+template <int HBM_> struct HaloShape {
+    static constexpr int HBM = HBM_;                         // output pixels per workgroup
+    static constexpr int HR = HBM_ == 512 ? 544 : 320;       // rows of one halo image (multiple of 32)
+    static constexpr int BST = HBM_ == 512 ? 3 : 4;          // weight ring stages; tap it+BST-1 is prefetched during tap it
+    static constexpr int WN = HBM_ == 512 ? 1 : 2;           // consumer wave grid (NCW / WN) x WN
+    static constexpr int NAP = HR * 8 / (NPW * 64);          // activation DMA instructions per producer thread per image
+};
 
 template <int N> __device__ __forceinline__ void halo_wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 }  // namespace
 
-template <int BN, int PREC, int DBG = 0, int ABL = 0>   // DBG: dev tool, per-workgroup cycle stamps (tools/halo_phase_cycles.py); ABL: timing ablations (wrong results)
+template <int BN, int PREC, int HBM_ = 256, int DBG = 0, int ABL = 0>   // DBG: dev tool, per-workgroup cycle stamps (tools/halo_phase_cycles.py); ABL: timing ablations (wrong results)
 __global__ void __launch_bounds__((NCW + NPW) * 64) conv_igemm_halo(const ConvArgs a) {
+    using SH = HaloShape<HBM_>;
+    constexpr int HBM = SH::HBM, HR = SH::HR, BST = SH::BST, WN = SH::WN, NAP = SH::NAP;
+    constexpr int PFD = BST - 1;                       // weight prefetch distance in taps
     constexpr int TM = 2;
-    constexpr int TN = BN / 64;
+    constexpr int TN = BN / (32 * WN);
+    static_assert(HBM == (NCW / WN) * TM * 32 && BN == WN * TN * 32, "wave grid");
     constexpr int A_BUF = HR * 32;                     // floats
     constexpr int B_STAGE = 32 * BN;                   // floats
     constexpr int B_BASE = 2 * A_BUF;
@@ -105,12 +122,15 @@ __global__ void __launch_bounds__((NCW + NPW) * 64) conv_igemm_halo(const ConvAr
         // =========================================================================================
         // Producer waves.  Iteration `it` (between the barriers of taps it-1 and it): issue the halo
         // image of the NEXT super-chunk if tap it opens one (its buffer was last read by the tap
-        // before), issue the weights of tap it+3 (their stage was last read by tap it-1), then wait
-        // until the own shares of everything tap it+1 reads have landed.
-        // Queue order per iteration j: [image if first(j)], weights j+3.  Needed at the barrier of
-        // iteration it: the weights of tap it+1 (issued at it-2) and the image tap it+1 may open,
+        // before), issue the weights of tap it+PFD (their stage was last read by tap it-1; PFD =
+        // BST-1 = 3, or 2 in the 512-pixel shape), then wait until the own shares of everything tap
+        // it+1 reads have landed.
+        // Queue order per iteration j: [image if first(j)], weights j+PFD.  Needed at the barrier of
+        // iteration it: the weights of tap it+1 (issued at it+1-PFD) and the image tap it+1 may open,
         // issued >= KW >= 3 iterations ago -- except inside the KW = 1 transform segment, where it
-        // was issued in this very iteration, before the weights of tap it+3.
+        // was issued in this very iteration, before the weights of tap it+PFD.  Younger than the
+        // weights of tap it+1 are PFD-1 weight groups and the images issued in the last PFD-1
+        // iterations (this one included).
         const int pw = wave - NCW, ptid = tid - NCW * 64;
         if constexpr (!(ABL & 64)) __builtin_amdgcn_s_setprio(3);   // the one wave per SIMD everybody waits for (measured +3 %)
         const int slot = lane & 7;
@@ -207,24 +227,26 @@ __global__ void __launch_bounds__((NCW + NPW) * 64) conv_igemm_halo(const ConvAr
         NH_ISSUE_A(0)
         NH_ISSUE_B(0)
         NH_ISSUE_B(1)
-        NH_ISSUE_B(2)
-        halo_wait_vmcnt<2 * GBP>();                     // image 0 and tap 0
+        if constexpr (PFD == 3) NH_ISSUE_B(2)
+        halo_wait_vmcnt<(PFD - 1) * GBP>();             // image 0 and tap 0
         __builtin_amdgcn_s_barrier();
         long long dbg_is = 0, dbg_vm = 0, dbg_bar = 0, dbg_t0 = 0;
         if constexpr (DBG) dbg_t0 = (long long)__builtin_amdgcn_s_memtime();
         bool prev_first = false;
+        int stB = PFD;                                  // ring stage of the tap being prefetched
         for (int it = 0; it < total; ++it) {
             const int KWc = segC ? 1 : KW0;
             const bool first = kwC == 0;
             long long tq0 = 0, tq1 = 0, tq2 = 0;
             if constexpr (DBG) tq0 = (long long)__builtin_amdgcn_s_memtime();
             if (first) NH_ISSUE_A(bufC ^ 1)
-            NH_ISSUE_B((it + 3) & (BST - 1))
+            NH_ISSUE_B(stB)
+            if (++stB == BST) stB = 0;
             if constexpr (DBG) tq1 = (long long)__builtin_amdgcn_s_memtime();
             if constexpr (ABL & (2 | 8)) halo_wait_vmcnt<0>();
             else if (KWc == 1) halo_wait_vmcnt<GBP>();
-            else if (first || prev_first) halo_wait_vmcnt<2 * GBP + NAP>();
-            else halo_wait_vmcnt<2 * GBP>();
+            else if (first || (PFD == 3 && prev_first)) halo_wait_vmcnt<(PFD - 1) * GBP + NAP>();
+            else halo_wait_vmcnt<(PFD - 1) * GBP>();
             if constexpr (DBG) tq2 = (long long)__builtin_amdgcn_s_memtime();
             __builtin_amdgcn_s_barrier();
             if constexpr (DBG) {
@@ -254,7 +276,7 @@ __global__ void __launch_bounds__((NCW + NPW) * 64) conv_igemm_halo(const ConvAr
     // Consumer waves.  Tile pixel r = wm*64 + t*32 + (lane&31) sits in halo row r + (KW-1)*i(r)
     // (+ kw per tap) while segment 0 runs, in row r for the transform segment; 16-byte piece p of a
     // row sits at slot p ^ ((row>>1)&7).
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WN, wn = wave % WN;
     const int g8 = lane >> 5;
     int jb0[TM], jb1[TM];
 #pragma unroll
@@ -329,8 +351,10 @@ __global__ void __launch_bounds__((NCW + NPW) * 64) conv_igemm_halo(const ConvAr
     long long dbg_bar = 0, dbg_t0 = 0;
     if constexpr (DBG) dbg_t0 = (long long)__builtin_amdgcn_s_memtime();
     NH_READ_HALF(0, 0)
+    int stC = 0;                                        // ring stage of tap `it`
     for (int it = 0; it < total; ++it) {
-        if constexpr (!(ABL & 16)) NH_READ_HALF(1, it & (BST - 1))
+        if constexpr (!(ABL & 16)) NH_READ_HALF(1, stC)
+        if (++stC == BST) stC = 0;
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (!(ABL & 32)) NH_MFMA_HALF(0)
         __builtin_amdgcn_sched_barrier(0);
@@ -345,7 +369,7 @@ __global__ void __launch_bounds__((NCW + NPW) * 64) conv_igemm_halo(const ConvAr
         }
         __builtin_amdgcn_sched_barrier(0);
         NH_NEXT_TAP()
-        if constexpr (!(ABL & 16)) NH_READ_HALF(0, (it + 1) & (BST - 1))   // (past the last tap: a harmless read)
+        if constexpr (!(ABL & 16)) NH_READ_HALF(0, stC)   // (past the last tap: a harmless read)
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (!(ABL & 32)) NH_MFMA_HALF(1)
         if constexpr ((ABL & 32) != 0) {                 // keep the operand reads alive
@@ -381,14 +405,19 @@ __global__ void __launch_bounds__((NCW + NPW) * 64) conv_igemm_halo(const ConvAr
     }
 }
 
-template <int BN, int PREC, int DBG = 0, int ABL = 0> static void launch_halo_t(const ConvArgs& a, hipStream_t s) {
-    constexpr size_t lds = (size_t)(2 * HR * 32 + BST * 32 * BN) * sizeof(float);
+template <int BN, int PREC, int HBM_ = 256, int DBG = 0, int ABL = 0> static void launch_halo_t(const ConvArgs& a, hipStream_t s) {
+    using SH = HaloShape<HBM_>;
+    constexpr size_t lds = (size_t)(2 * SH::HR * 32 + SH::BST * 32 * BN) * sizeof(float);
+    static_assert(lds <= 160 * 1024, "LDS of a gfx950 CU");
     static unsigned long long attr_devices = 0;
-    set_max_dynamic_lds(reinterpret_cast<const void*>(&conv_igemm_halo<BN, PREC, DBG, ABL>), lds, &attr_devices, "conv_igemm_halo");
-    const int mtiles = (a.M + HBM - 1) / HBM;
+    set_max_dynamic_lds(reinterpret_cast<const void*>(&conv_igemm_halo<BN, PREC, HBM_, DBG, ABL>), lds, &attr_devices, "conv_igemm_halo");
+    const int mtiles = (a.M + SH::HBM - 1) / SH::HBM;
     const int grid = mtiles * (a.N / BN);
-    NHANS_LAUNCH("conv_igemm_halo", (conv_igemm_halo<BN, PREC, DBG, ABL>), dim3(grid), dim3((NCW + NPW) * 64), lds, s, a);
+    NHANS_LAUNCH("conv_igemm_halo", (conv_igemm_halo<BN, PREC, HBM_, DBG, ABL>), dim3(grid), dim3((NCW + NPW) * 64), lds, s, a);
 }
+
+// pixels per workgroup tile for this conv: 512 for the 64-channel layers, 256 otherwise
+static int halo_tile_pixels(const ConvArgs& a) { return (a.N % 128 != 0 && a.halo64_tile512) ? 512 : 256; }
 
 bool conv_igemm_halo_eligible(const ConvArgs& a) {
     const ConvSeg& g = a.seg[0];
@@ -403,25 +432,30 @@ bool conv_igemm_halo_eligible(const ConvArgs& a) {
         if (elems + 65536.0 >= 2147483648.0) return false;
     }
     // rows of the halo image of a 256-pixel run that starts at the last column of an image row
-    const int nrows = (a.Wo - 1 + HBM - 1) / a.Wo + 1;
-    return HBM + (g.KW - 1) * nrows <= HR;
+    const int hbm = halo_tile_pixels(a);
+    const int nrows = (a.Wo - 1 + hbm - 1) / a.Wo + 1;
+    return hbm + (g.KW - 1) * nrows <= (hbm == 512 ? HaloShape<512>::HR : HaloShape<256>::HR);
 }
 
 void launch_conv_igemm_halo(const ConvArgs& a0, hipStream_t s) {
     ConvArgs a = a0;
     a.fdWP = make_fastdiv((uint32_t)(a.Wo + a.seg[0].KW - 1));
     const bool wide = a.N % 128 == 0;
+    if (!wide && halo_tile_pixels(a) == 512) {          // 64-channel convs: 512-pixel tiles
+        if (a.prec == 1) launch_halo_t<64, 1, 512>(a, s); else launch_halo_t<64, 0, 512>(a, s);
+        return;
+    }
 #ifdef NHANS_DEV
     const int abl = dev_ablate();
     if (a.prec == 1 && a.dbg) {     // cycle stamps, optionally of an ablated loop
-#define NH_DBG_CASE(V) case V: if (wide) launch_halo_t<128, 1, 1, V>(a, s); else launch_halo_t<64, 1, 1, V>(a, s); break;
+#define NH_DBG_CASE(V) case V: if (wide) launch_halo_t<128, 1, 256, 1, V>(a, s); else launch_halo_t<64, 1, 256, 1, V>(a, s); break;
         switch (abl) {
             NH_DBG_CASE(10) NH_DBG_CASE(16) NH_DBG_CASE(32) NH_DBG_CASE(48)
-            default: if (wide) launch_halo_t<128, 1, 1>(a, s); else launch_halo_t<64, 1, 1>(a, s);
+            default: if (wide) launch_halo_t<128, 1, 256, 1>(a, s); else launch_halo_t<64, 1, 256, 1>(a, s);
         }
 #undef NH_DBG_CASE
     } else if (a.prec == 1) {
-#define NH_ABL_CASE(V) case V: if (wide) launch_halo_t<128, 1, 0, V>(a, s); else launch_halo_t<64, 1, 0, V>(a, s); break;
+#define NH_ABL_CASE(V) case V: if (wide) launch_halo_t<128, 1, 256, 0, V>(a, s); else launch_halo_t<64, 1, 256, 0, V>(a, s); break;
         switch (abl) {              // timing experiments only: results are wrong for abl != 0
             NH_ABL_CASE(1) NH_ABL_CASE(2) NH_ABL_CASE(4) NH_ABL_CASE(5) NH_ABL_CASE(8) NH_ABL_CASE(10)
             NH_ABL_CASE(16) NH_ABL_CASE(32) NH_ABL_CASE(48) NH_ABL_CASE(64)

@@ -114,7 +114,8 @@ struct nhans_ctx {
     std::vector<hipEvent_t> event_pool;
 
     int prec = 0;           // 0: f32 MFMA, 1: split-f16 x3 MFMA (activations in split NHWC)
-    int conv_variant = -1;  // 0: 128-pixel register-staged conv kernel, 1: 256-pixel LDS-DMA kernel,
+    int conv_variant = -1;  // 3: as 2 but the 64-channel convs on 2-D 256-pixel tiles (conv_igemm_halo2d.hip);
+                            // 0: 128-pixel register-staged conv kernel, 1: 256-pixel LDS-DMA kernel,
                             // 2: halo-reuse / wave-specialised LDS-DMA kernel where the conv allows it, else 1;
                             // -1: automatic (measured best: 2 for split-f16, register-staged for f32)
     long long* dbg = nullptr;   // NHANS_DEV builds: per-workgroup cycle stamps of the last conv launch
@@ -687,7 +688,7 @@ int nhans_set_option(nhans_ctx* c, const char* key, int64_t value) {
         c->dbg = reinterpret_cast<long long*>(static_cast<intptr_t>(value));
     }
     else if (k == "conv_variant") {
-        if (value < -1 || value > 2) return fail(NHANS_EINVAL, "conv_variant must be -1 (auto), 0, 1 or 2");
+        if (value < -1 || value > 3) return fail(NHANS_EINVAL, "conv_variant must be -1 (auto), 0, 1, 2 or 3");
         c->conv_variant = (int)value;
     }
     else if (k == "precision") {

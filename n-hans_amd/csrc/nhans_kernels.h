@@ -103,7 +103,9 @@ struct ConvArgs {
     const float* ws;       // prec 1: per-channel power-of-two that undoes the weight pre-scaling
     int* sat;              // prec 1: device flag word, kSatActivation is OR-ed in when a stored activation saturates
     int variant;           // 0: 128-pixel / 4-wave register-staged kernel, 1: 256-pixel / 8-wave LDS-DMA kernel,
-                           // 2: LDS-DMA kernel with halo reuse across the KW taps where the conv allows it
+                           // 2, 3: LDS-DMA kernel with halo reuse across the KW taps where the conv allows it
+    int halo64_tile512;    // halo kernel, 64-channel convs: 512-pixel tiles (variant 2) instead of the 2-D
+                           // 256-pixel tiles of conv_igemm_halo2d.hip / 256-pixel runs (variant 3)
     long long* dbg;        // NHANS_DEV builds only: 4 s_memtime stamps per workgroup [start, loop, epilogue, end]
     FastDiv fdHoWo, fdWo;
     FastDiv fdWP;          // Wo + KW - 1 (filled in by launch_conv_igemm_halo)

@@ -141,7 +141,7 @@ def test_ten_second_clip_selected_frames(eng_d):
     assert np.abs(lg.cpu().numpy()[fr] - g["logits"]).max() < LOGIT_TOL
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3])
 @pytest.mark.parametrize("prec", ["f32", "f16x3"])
 def test_every_conv_kernel_variant(_eng_d, prec, variant):
     """The three conv kernels (register-staged, LDS-DMA, halo + producer/consumer waves) in both
