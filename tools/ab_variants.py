@@ -21,7 +21,7 @@ def main():
     p.add_argument("--rounds", type=int, default=3)
     p.add_argument("--variants", type=int, nargs="+", default=[2, 3])
     p.add_argument("--kind", default="denoiser")
-    p.add_argument("--stagger", type=int, nargs="+", default=None, help="A/B the start-up stagger instead (cycles)")
+    p.add_argument("--option", default="conv_variant", help="the nhans_set_option key to A/B (values: --variants)")
     a = p.parse_args()
     W = weights.synthetic_weights(a.kind, 7)
     eng = engine.Engine(a.kind, W, precision="f16x3")
@@ -33,12 +33,10 @@ def main():
     run()
     torch.cuda.synchronize()
     eng.set_option("profile", 1)
-    if a.stagger is not None:
-        a.variants = a.stagger
     res = {v: [] for v in a.variants}
     for r in range(a.rounds):
         for v in a.variants:
-            eng.set_option("stagger" if a.stagger is not None else "conv_variant", v)
+            eng.set_option(a.option, v)
             eng.profile_reset()
             run()
             torch.cuda.synchronize()
