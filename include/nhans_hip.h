@@ -87,6 +87,10 @@ void nhans_destroy(nhans_ctx* ctx);
  *           256-pixel kernel; 2: halo-reuse kernel with producer/consumer waves where the conv
  *           allows it (512-pixel tiles for the 64-channel convs), else 1; 3: as 2 with the
  *           64-channel convs on 2-D 256-pixel tiles -- same results within rounding, different speed).
+ *          "epilogue_wide" (1, default: split-f16 epilogues move 8 channels = 16-byte pieces per thread;
+ *           0: 4 channels -- identical bits, kept for A/B),
+ *          "consumer_interleave" (1, default: the MFMA waves of the halo kernels issue their LDS operand
+ *           reads between their MFMAs; 0: read block then MFMA block -- identical bits, kept for A/B).
  * (A `make DEV=1` build adds "debug_cycles_ptr" and the NHANS_ABLATE / NHANS_HALO2D environment
  * switches used by tools/; the default build has no developer hooks and reads no environment.)
  * Besides the workspace a context holds 64 MB of split-K scratch for the few launches that are

@@ -124,12 +124,127 @@ __device__ __forceinline__ void conv_epilogue_sweep(const ConvArgs& a, const flo
     }
 }
 
+// The same sweep with 8 channels per thread, for split-NHWC outputs (the f16x3 main path).  In the
+// split layout a 32-channel group of a pixel is one 128-byte line = 32 hi halfs + 32 lo halfs; with 4
+// channels per thread every residual load and every store is an 8-byte piece (two per pass each),
+// with 8 channels they are 16-byte pieces and there are half as many memory instructions per byte --
+// the epilogue is bound by memory-instruction issue, not by bytes (8-byte accesses run at 0.54-0.70 x
+// the 16-byte rate on this chip).  Same arithmetic per element in the same order: bitwise identical.
+// IDM: 0 none, 1 split-NHWC tensor, 3 one-channel image.
+// Software-pipelined over groups of GP passes: the global loads of group g+1 (position table, residual,
+// and -- unless the tile lies in one clip, HOIST -- the per-clip bias) are in flight while group g is
+// combined with its accumulators and stored, so the load path of the CU (64 B/clk through the L1) never
+// idles between groups; measured on the round-1 sweep (two groups, each "issue every load, wait,
+// store"): 6.8 k cycles from the issue of a group's loads to their arrival, 23 k for the sweep of a
+// 512 x 64 tile against 6-8 k of L1 time.
+template <int IDM> struct Epi8Raw {               // what one pass has in flight
+    f32x4 c0, c1, t0, t1;
+    f16x8 h, l;
+    float sv;
+    int m, p;
+};
+
+template <int PREC, int IDM, int HOIST, int PP, int PASSES, int LDC>
+__device__ __forceinline__ void conv_epilogue_sweep8(const ConvArgs& a, const float* ct, const int4* rowinfo,
+                                                     int prow, int c8, int n, long long* es = nullptr) {
+    constexpr int GP = PASSES % 2 == 0 ? 2 : 1;
+    constexpr int NG = PASSES / GP;
+    const int f_tf = a.tf ? 1 : 0;
+    const float* __restrict__ cbp = a.cb;
+    const float* __restrict__ tfp = a.tf ? a.tf : a.zero;
+    f32x4 ws0 = {1.f, 1.f, 1.f, 1.f}, ws1 = ws0, iw0 = {0.f, 0.f, 0.f, 0.f}, iw1 = iw0;
+    if constexpr (PREC == 1) { ws0 = *reinterpret_cast<const f32x4*>(a.ws + n); ws1 = *reinterpret_cast<const f32x4*>(a.ws + n + 4); }
+    if constexpr (IDM != 0) { iw0 = *reinterpret_cast<const f32x4*>(a.idw + n); iw1 = *reinterpret_cast<const f32x4*>(a.idw + n + 4); }
+    f32x4 hc0 = {0.f, 0.f, 0.f, 0.f}, hc1 = hc0;             // HOIST: the one clip's bias, loaded once
+    if constexpr (HOIST) {
+        const int cx = rowinfo[0].x;
+        hc0 = *reinterpret_cast<const f32x4*>(cbp + cx + n);
+        hc1 = *reinterpret_cast<const f32x4*>(cbp + cx + n + 4);
+    }
+    const int hoff = (n >> 5) * 64 + (n & 31);                // half index inside a split-NHWC pixel (n % 8 == 0)
+    const float lo_clamp = a.relu ? 0.f : -3.0e38f;
+    bool sat = false;
+
+    auto issue = [&](int g, Epi8Raw<IDM> (&r)[GP]) {
+#pragma unroll
+        for (int u = 0; u < GP; ++u) {
+            const int p = (g * GP + u) * PP + prow;
+            const int4 ri = rowinfo[p];
+            r[u].p = p;
+            r[u].m = ri.z;
+            const int mc = ri.z < 0 ? 0 : ri.z;
+            if constexpr (!HOIST) {
+                r[u].c0 = *reinterpret_cast<const f32x4*>(cbp + ri.x + n);
+                r[u].c1 = *reinterpret_cast<const f32x4*>(cbp + ri.x + n + 4);
+            }
+            r[u].t0 = *reinterpret_cast<const f32x4*>(tfp + (ri.y + n) * f_tf);
+            r[u].t1 = *reinterpret_cast<const f32x4*>(tfp + (ri.y + n) * f_tf + 4 * f_tf);
+            if constexpr (IDM == 1) {
+                const _Float16* hp = reinterpret_cast<const _Float16*>(a.id + (size_t)mc * a.id_ld) + hoff;
+                r[u].h = *reinterpret_cast<const f16x8*>(hp);
+                r[u].l = *reinterpret_cast<const f16x8*>(hp + 32);
+            } else if constexpr (IDM == 3) {
+                r[u].sv = a.id[ri.w];
+            }
+        }
+    };
+    auto finish = [&](Epi8Raw<IDM> (&r)[GP]) {
+#pragma unroll
+        for (int u = 0; u < GP; ++u) {
+            const f32x4 av0 = *reinterpret_cast<const f32x4*>(ct + r[u].p * LDC + c8 * 8);
+            const f32x4 av1 = *reinterpret_cast<const f32x4*>(ct + r[u].p * LDC + c8 * 8 + 4);
+            f32x4 i0 = {0.f, 0.f, 0.f, 0.f}, i1 = i0;
+            if constexpr (IDM == 1) {
+                const f16x8 h = r[u].h, l = r[u].l;
+                i0 = f32x4{(float)h[0] + (float)l[0], (float)h[1] + (float)l[1], (float)h[2] + (float)l[2], (float)h[3] + (float)l[3]};
+                i1 = f32x4{(float)h[4] + (float)l[4], (float)h[5] + (float)l[5], (float)h[6] + (float)l[6], (float)h[7] + (float)l[7]};
+            } else if constexpr (IDM == 3) {
+                i0 = f32x4{r[u].sv, r[u].sv, r[u].sv, r[u].sv};
+                i1 = i0;
+            }
+            const f32x4 c0 = HOIST ? hc0 : r[u].c0, c1 = HOIST ? hc1 : r[u].c1;
+            const f32x4 r0 = ((av0 * ws0 + c0) + r[u].t0) + iw0 * i0;
+            const f32x4 r1 = ((av1 * ws1 + c1) + r[u].t1) + iw1 * i1;
+            if (r[u].m >= 0) {
+                f16x8 h, l;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float y = fmaxf(e < 4 ? r0[e] : r1[e - 4], lo_clamp);
+                    sat |= !(fabsf(y) < 65504.f);
+                    const float yc = fminf(fmaxf(y, -65504.f), 65504.f);
+                    h[e] = (_Float16)yc;
+                    l[e] = (_Float16)(yc - (float)h[e]);
+                }
+                _Float16* dst = reinterpret_cast<_Float16*>(a.out + (size_t)r[u].m * a.ldo) + hoff;
+                *reinterpret_cast<f16x8*>(dst) = h;
+                *reinterpret_cast<f16x8*>(dst + 32) = l;
+            }
+        }
+    };
+
+    Epi8Raw<IDM> ra[GP], rb[GP];                      // two groups in flight, statically named
+    issue(0, ra);
+#pragma unroll
+    for (int g = 0; g < NG; g += 2) {
+        if (g + 1 < NG) issue(g + 1, rb);
+        finish(ra);
+        if (kDev && es && g == 0) {                      // dev stamp: the first group is through
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            es[2] = (long long)__builtin_amdgcn_s_memtime();
+        }
+        if (g + 2 < NG) issue(g + 2, ra);
+        if (g + 1 < NG) finish(rb);
+    }
+    if (sat && a.sat) atomicOr(a.sat, kSatActivation);
+}
+
 // acc[i][j]: 32x32 MFMA tile (i: pixels, j: channels) of the wave whose tile-local origin is
 // (row_base, col_base); n_tile0: first channel of the workgroup tile; the caller has passed a
 // workgroup barrier after its last LDS read of the K loop.
 template <int TM, int TN, int PREC, int NTHREADS, int BMROWS, int BNCOLS>
 __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[TM][TN], float* smem, EpiTile tile,
-                                              int row_base, int col_base, int n_tile0, int tid, int lane) {
+                                              int row_base, int col_base, int n_tile0, int tid, int lane,
+                                              long long* es = nullptr /* dev stamps: [LDS written, barrier passed, group 0 loaded] */) {
     constexpr int LDC = BNCOLS + 4;
     constexpr int C4 = BNCOLS / 4;                    // threads along the channels of one pixel
     constexpr int PP = NTHREADS / C4;                 // pixels per pass
@@ -151,7 +266,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[T
     // 2. per-pixel (clip, h, w, 1-channel residual index)
     if (tid < BMROWS) {
         const int mz = tile(tid, a);
-        const int m = mz < 0 ? 0 : mz;
+        const int m = mz < 0 ? tile(0, a) : mz;          // (slots past the end look like the tile's first pixel; never stored)
         const uint32_t b = fd_div((uint32_t)m, a.fdHoWo);
         const uint32_t rem = (uint32_t)m - b * a.fdHoWo.d;
         const uint32_t ho = fd_div(rem, a.fdWo);
@@ -160,7 +275,9 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[T
         const int ids = (int)((b * a.idH + ho * a.idsh) * a.idW + wo * a.idsw);
         rowinfo[tid] = make_int4(clip * a.cb_stride, (int)rem * a.N, mz, ids);
     }
+    if (kDev && es) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); es[0] = (long long)__builtin_amdgcn_s_memtime(); }
     __syncthreads();
+    if (kDev && es) es[1] = (long long)__builtin_amdgcn_s_memtime();
 
     // 3. row-major sweep: thread = (pixel within pass, 4 channels)
     const int c4 = tid % C4, prow = tid / C4;
@@ -171,7 +288,24 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[T
     const float* __restrict__ tfp = a.tf ? a.tf : a.zero;     // an absent table reads the zero page
     const bool vec = (a.Nreal == a.N) && !a.aux && (a.out_split || (a.ldo & 3) == 0) &&
                      (a.id_mode != 1 || id_split || (a.id_ld & 3) == 0);
-    if (vec) {
+    constexpr int C8 = BNCOLS / 8, PP8 = NTHREADS / C8, PASSES8 = BMROWS / PP8;
+    if (vec && a.epi8 && a.out_split && (a.id_mode == 0 || id_split || a.id_mode == 2)) {
+        // split-NHWC output (the f16x3 main path): 8 channels per thread, 16-byte pieces throughout
+        const int c8 = tid % C8, prow8 = tid / C8;
+        const int n8 = n_tile0 + c8 * 8;
+        // one clip for the whole tile (pixels are ordered by clip, so first == last decides; rows past
+        // the end of the tensor carry the first row's clip): its bias vector is loaded once per thread
+        const bool one_clip = rowinfo[0].x == rowinfo[BMROWS - 1].x;
+        const int mode8 = (a.id_mode == 0 ? 0 : a.id_mode == 1 ? 1 : 2) * 2 + (one_clip ? 1 : 0);
+        switch (mode8) {
+            case 0: conv_epilogue_sweep8<PREC, 0, 0, PP8, PASSES8, LDC>(a, ct, rowinfo, prow8, c8, n8, es); break;
+            case 1: conv_epilogue_sweep8<PREC, 0, 1, PP8, PASSES8, LDC>(a, ct, rowinfo, prow8, c8, n8, es); break;
+            case 2: conv_epilogue_sweep8<PREC, 1, 0, PP8, PASSES8, LDC>(a, ct, rowinfo, prow8, c8, n8, es); break;
+            case 3: conv_epilogue_sweep8<PREC, 1, 1, PP8, PASSES8, LDC>(a, ct, rowinfo, prow8, c8, n8, es); break;
+            case 4: conv_epilogue_sweep8<PREC, 3, 0, PP8, PASSES8, LDC>(a, ct, rowinfo, prow8, c8, n8, es); break;
+            default: conv_epilogue_sweep8<PREC, 3, 1, PP8, PASSES8, LDC>(a, ct, rowinfo, prow8, c8, n8, es); break;
+        }
+    } else if (vec) {
         // residual mode / output layout are resolved once, outside the loops: the sweep below is one
         // straight-line block per group of passes, so all its loads issue before the first wait
         const int mode = (a.id_mode == 1 ? (id_split ? 1 : 2) : a.id_mode == 2 ? 3 : 0) * 2 + (a.out_split ? 1 : 0);

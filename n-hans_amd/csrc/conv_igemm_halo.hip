@@ -59,6 +59,16 @@ template <int HBM_> struct HaloShape {
     static constexpr int NAP = HR * 8 / (NPW * 64);          // activation DMA instructions per producer thread per image
 };
 
+// scheduling pattern of a consumer half: ND operand reads spread evenly between NM MFMAs
+// (sched_group_barrier masks: 0x008 MFMA, 0x100 DS read)
+template <int I, int NM, int ND> __device__ __forceinline__ void halo_pin_interleave() {
+    if constexpr (I < ND) {
+        __builtin_amdgcn_sched_group_barrier(0x008, (I + 1) * NM / ND - I * NM / ND, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        halo_pin_interleave<I + 1, NM, ND>();
+    }
+}
+
 template <int N> __device__ __forceinline__ void halo_wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
@@ -343,20 +353,37 @@ __global__ void __launch_bounds__((NCW + NPW) * 64) conv_igemm_halo(const ConvAr
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[t][j][r] = 0.f;
 
-    // One tap `it`: read half 1 of tap it; MFMAs of half 0; barrier (the producers have seen the
-    // operands of tap it+1 land, every consumer holds all of tap it in registers -- which frees its
-    // weight stage and, after the last tap of a super-chunk, its halo buffer); read half 0 of tap
-    // it+1; MFMAs of half 1.
+    // One tap `it`: MFMAs of half 0 with the operand reads of half 1 of tap it issued BETWEEN them;
+    // barrier (the producers have seen the operands of tap it+1 land, every consumer holds all of
+    // tap it in registers -- which frees its weight stage and, after the last tap of a super-chunk, its
+    // halo buffer); MFMAs of half 1 with the reads of half 0 of tap it+1 between them.
+    // The interleave is pinned (sched_group_barrier: NM/ND MFMAs, one ds_read, ...).  With a read block
+    // in front of an MFMA block -- the round-1 arrangement -- all eight waves hammer the LDS while the
+    // matrix pipes idle and then the reverse; a wave's reads issued in the shadow of its own 32-cycle
+    // MFMAs cost the pipe nothing (tools/ubench/fat_loop.hip: 2,436 -> 2,069 cycles per tap beside
+    // 28 KB of LDS-DMA, MFMA floor 1,536).
     __builtin_amdgcn_s_barrier();                       // image 0 and tap 0 have landed
     long long dbg_bar = 0, dbg_t0 = 0;
     if constexpr (DBG) dbg_t0 = (long long)__builtin_amdgcn_s_memtime();
+    constexpr int NM = KH_ * TM * TN * (PREC == 1 ? 3 : 4);         // MFMAs per half
+    constexpr int ND = KH_ * (TM + TN) * (PREC == 1 ? 2 : 1);       // ds_read_b128 per half
+    static_assert(NM >= ND, "interleave pattern");
+#define NH_PIN_INTERLEAVE()                                                                        \
+    if constexpr (!(ABL & (16 | 32 | 128))) halo_pin_interleave<0, NM, ND>();
     NH_READ_HALF(0, 0)
     int stC = 0;                                        // ring stage of tap `it`
     for (int it = 0; it < total; ++it) {
-        if constexpr (!(ABL & 16)) NH_READ_HALF(1, stC)
-        if (++stC == BST) stC = 0;
         __builtin_amdgcn_sched_barrier(0);
-        if constexpr (!(ABL & 32)) NH_MFMA_HALF(0)
+        if constexpr ((ABL & 128) != 0) {                // round-1 order: read block, then MFMA block
+            NH_READ_HALF(1, stC)
+            __builtin_amdgcn_sched_barrier(0);
+            NH_MFMA_HALF(0)
+        } else {
+            if constexpr (!(ABL & 32)) NH_MFMA_HALF(0)
+            if constexpr (!(ABL & 16)) NH_READ_HALF(1, stC)
+            NH_PIN_INTERLEAVE()
+        }
+        if (++stC == BST) stC = 0;
         __builtin_amdgcn_sched_barrier(0);
         long long tq0 = 0;
         if constexpr (DBG) tq0 = (long long)__builtin_amdgcn_s_memtime();
@@ -369,9 +396,15 @@ __global__ void __launch_bounds__((NCW + NPW) * 64) conv_igemm_halo(const ConvAr
         }
         __builtin_amdgcn_sched_barrier(0);
         NH_NEXT_TAP()
-        if constexpr (!(ABL & 16)) NH_READ_HALF(0, stC)   // (past the last tap: a harmless read)
-        __builtin_amdgcn_sched_barrier(0);
-        if constexpr (!(ABL & 32)) NH_MFMA_HALF(1)
+        if constexpr ((ABL & 128) != 0) {
+            NH_READ_HALF(0, stC)
+            __builtin_amdgcn_sched_barrier(0);
+            NH_MFMA_HALF(1)
+        } else {
+            if constexpr (!(ABL & 32)) NH_MFMA_HALF(1)
+            if constexpr (!(ABL & 16)) NH_READ_HALF(0, stC)   // (past the last tap: a harmless read)
+            NH_PIN_INTERLEAVE()
+        }
         if constexpr ((ABL & 32) != 0) {                 // keep the operand reads alive
             float k_ = 0.f;
             _Pragma("unroll") for (int s = 0; s < KS; ++s) {
@@ -393,15 +426,24 @@ __global__ void __launch_bounds__((NCW + NPW) * 64) conv_igemm_halo(const ConvAr
 #undef NH_READ_HALF
 #undef NH_MFMA_HALF
 #undef NH_NEXT_TAP
+#undef NH_PIN_INTERLEAVE
 
     long long dbg_epi = 0;
+    long long es[3] = {0, 0, 0};
     if constexpr (DBG) dbg_epi = (long long)__builtin_amdgcn_s_memtime();
     static_assert(conv_epilogue_lds_bytes<HBM, BN>() <= (size_t)(2 * A_BUF + BST * B_STAGE) * sizeof(float), "epilogue LDS");
-    conv_epilogue<TM, TN, PREC, NCW * 64, HBM, BN>(a, acc, smem, EpiTile{m0, 0, 0, 0, 0, 0}, wm * 64, wn * TN * 32, nt * BN, tid, lane);
+    conv_epilogue<TM, TN, PREC, NCW * 64, HBM, BN>(a, acc, smem, EpiTile{m0, 0, 0, 0, 0, 0}, wm * 64, wn * TN * 32, nt * BN, tid, lane,
+                                                   DBG ? es : nullptr);
     if constexpr (DBG) {                                // [.., prologue cycles, epilogue cycles, ..]
+        const long long t_issued = (long long)__builtin_amdgcn_s_memtime();
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (a.dbg && lane == 0)
-            a.dbg[((size_t)blockIdx.x * (NCW + NPW) + wave) * 4 + 2] = (long long)__builtin_amdgcn_s_memtime() - dbg_epi;
+        if (a.dbg && lane == 0) {
+            const long long t_end = (long long)__builtin_amdgcn_s_memtime();
+            a.dbg[((size_t)blockIdx.x * (NCW + NPW) + wave) * 4 + 2] = t_end - dbg_epi;
+            // epilogue phases: LDS written | barrier passed | group 0 loaded | all stores issued | drained
+            long long* e = a.dbg + (size_t)(4 << 20) + ((size_t)blockIdx.x * (NCW + NPW) + wave) * 8;
+            e[0] = es[0] - dbg_epi; e[1] = es[1] - dbg_epi; e[2] = es[2] - dbg_epi; e[3] = t_issued - dbg_epi; e[4] = t_end - dbg_epi;
+        }
     }
 }
 
@@ -441,7 +483,16 @@ void launch_conv_igemm_halo(const ConvArgs& a0, hipStream_t s) {
     ConvArgs a = a0;
     a.fdWP = make_fastdiv((uint32_t)(a.Wo + a.seg[0].KW - 1));
     const bool wide = a.N % 128 == 0;
+    if (!a.ilv && a.prec == 1) {                        // A/B knob: round-1 instruction order
+        if (!wide && halo_tile_pixels(a) == 512) launch_halo_t<64, 1, 512, 0, 128>(a, s);
+        else if (wide) launch_halo_t<128, 1, 256, 0, 128>(a, s);
+        else launch_halo_t<64, 1, 256, 0, 128>(a, s);
+        return;
+    }
     if (!wide && halo_tile_pixels(a) == 512) {          // 64-channel convs: 512-pixel tiles
+#ifdef NHANS_DEV
+        if (a.prec == 1 && a.dbg) { launch_halo_t<64, 1, 512, 1>(a, s); return; }
+#endif
         if (a.prec == 1) launch_halo_t<64, 1, 512>(a, s); else launch_halo_t<64, 0, 512>(a, s);
         return;
     }
@@ -450,7 +501,7 @@ void launch_conv_igemm_halo(const ConvArgs& a0, hipStream_t s) {
     if (a.prec == 1 && a.dbg) {     // cycle stamps, optionally of an ablated loop
 #define NH_DBG_CASE(V) case V: if (wide) launch_halo_t<128, 1, 256, 1, V>(a, s); else launch_halo_t<64, 1, 256, 1, V>(a, s); break;
         switch (abl) {
-            NH_DBG_CASE(10) NH_DBG_CASE(16) NH_DBG_CASE(32) NH_DBG_CASE(48)
+            NH_DBG_CASE(10) NH_DBG_CASE(16) NH_DBG_CASE(32) NH_DBG_CASE(48) NH_DBG_CASE(128)
             default: if (wide) launch_halo_t<128, 1, 256, 1>(a, s); else launch_halo_t<64, 1, 256, 1>(a, s);
         }
 #undef NH_DBG_CASE

@@ -118,6 +118,8 @@ struct nhans_ctx {
                             // 0: 128-pixel register-staged conv kernel, 1: 256-pixel LDS-DMA kernel,
                             // 2: halo-reuse / wave-specialised LDS-DMA kernel where the conv allows it, else 1;
                             // -1: automatic (measured best: 2 for split-f16, register-staged for f32)
+    int epi8 = 1;               // ConvArgs::epi8
+    int ilv = 1;                // ConvArgs::ilv
     long long* dbg = nullptr;   // NHANS_DEV builds: per-workgroup cycle stamps of the last conv launch
     int* status_dev = nullptr;  // sticky NHANS_STATUS_* bits set by kernels (nhans_take_status)
     // ordering of consecutive calls that share the workspace (see include/nhans_hip.h)
@@ -219,6 +221,8 @@ void fill_epilogue_defaults(nhans_ctx* c, ConvArgs& a) {
     a.prec = c->prec; a.out_split = c->prec; a.id_split = 0; a.ws = nullptr;
     a.variant = c->conv_variant >= 0 ? c->conv_variant : (c->prec == 1 ? 2 : 0);
     a.dbg = kDev ? c->dbg : nullptr;
+    a.epi8 = c->epi8;
+    a.ilv = c->ilv;
     a.kscratch = c->kscratch; a.kscratch_bytes = c->kscratch_bytes; a.kcounter = c->kcounter; a.kcounter_n = c->kcounter_n; a.kgroup = 0;
 }
 
@@ -687,6 +691,8 @@ int nhans_set_option(nhans_ctx* c, const char* key, int64_t value) {
         if (!kDev) return fail(NHANS_EINVAL, "debug_cycles_ptr exists only in a NHANS_DEV build (make DEV=1)");
         c->dbg = reinterpret_cast<long long*>(static_cast<intptr_t>(value));
     }
+    else if (k == "epilogue_wide") c->epi8 = value != 0;
+    else if (k == "consumer_interleave") c->ilv = value != 0;
     else if (k == "conv_variant") {
         if (value < -1 || value > 3) return fail(NHANS_EINVAL, "conv_variant must be -1 (auto), 0, 1, 2 or 3");
         c->conv_variant = (int)value;

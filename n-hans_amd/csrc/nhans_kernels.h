@@ -104,6 +104,10 @@ struct ConvArgs {
     int* sat;              // prec 1: device flag word, kSatActivation is OR-ed in when a stored activation saturates
     int variant;           // 0: 128-pixel / 4-wave register-staged kernel, 1: 256-pixel / 8-wave LDS-DMA kernel,
                            // 2, 3: LDS-DMA kernel with halo reuse across the KW taps where the conv allows it
+    int epi8;              // split-NHWC outputs: 8 channels per thread in the epilogue sweep (16-byte pieces), default;
+                           // 0 = the 4-channel sweep (A/B and parity cross-check; same bits)
+    int ilv;               // halo kernels: operand reads interleaved between the MFMAs (default 1); 0 = read block
+                           // then MFMA block (the round-1 order; A/B knob, same bits)
     int halo64_tile512;    // halo kernel, 64-channel convs: 512-pixel tiles (variant 2) instead of the 2-D
                            // 256-pixel tiles of conv_igemm_halo2d.hip / 256-pixel runs (variant 3)
     long long* dbg;        // NHANS_DEV builds only: 4 s_memtime stamps per workgroup [start, loop, epilogue, end]

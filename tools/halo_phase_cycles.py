@@ -31,7 +31,8 @@ def main():
         torch.cuda.synchronize()
     g = spec.main_geometry()[block]
     bn = 128 if g["cout"] >= 128 else 64
-    nblk = -(-(frames * g["hout"] * g["wout"]) // 256) * (g["cout"] // bn)
+    tile = 256 if g["cout"] >= 128 or os.environ["NHANS_CONV_VARIANT"] != "2" else 512
+    nblk = -(-(frames * g["hout"] * g["wout"]) // tile) * (g["cout"] // bn)
     d = dbg.cpu().numpy()[:nblk * 48].reshape(nblk, 12, 4).astype(np.float64)   # the last launch = this block's conv2
     taps = g["kh"] * g["kw"] * g["cout"] // 32 + (g["cin"] // 32 if g["cin"] not in (1, g["cout"]) else 0)
     m = d.mean(0) / taps
@@ -39,6 +40,10 @@ def main():
     for w in range(8):
         print("  consumer wave %d: loop %.0f | lgkm+barrier %.0f | reads+MFMA %.0f   || per workgroup: prologue %.0f, K loop %.0f, epilogue %.0f cycles"
               % (w, m[w, 0], m[w, 3], m[w, 0] - m[w, 3], m[w, 1] * taps, m[w, 0] * taps, m[w, 2] * taps))
+    e = dbg.cpu().numpy()[(4 << 20):(4 << 20) + nblk * 96].reshape(nblk, 12, 8).astype(np.float64).mean(0)
+    for w in (0, 7):
+        print("  epilogue of consumer wave %d, cycles from its start: accumulators in LDS %.0f | barrier passed %.0f | first group of loads "
+              "arrived %.0f | all stores issued %.0f | stores drained %.0f" % (w, e[w, 0], e[w, 1], e[w, 2], e[w, 3], e[w, 4]))
     for w in range(8, 12):
         print("  producer wave %d: loop %.0f | DMA issue %.0f | vmcnt wait %.0f | barrier %.0f" % (w, m[w, 0], m[w, 1], m[w, 2], m[w, 3]))
 
