@@ -21,6 +21,18 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));   // native vector: sta
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 
+// Scheduling pattern of one half of a K-loop step: ND operand reads (ds_read_b128) spread evenly between
+// NM MFMAs (sched_group_barrier masks: 0x008 MFMA, 0x100 DS read).  A wave's LDS reads issued in the
+// shadow of its own 32-cycle MFMAs cost the matrix pipe nothing; a block of reads in front of a block of
+// MFMAs makes all waves hammer the LDS while the pipes idle and then the reverse.
+template <int I, int NM, int ND> __device__ __forceinline__ void pin_reads_between_mfmas() {
+    if constexpr (I < ND) {
+        __builtin_amdgcn_sched_group_barrier(0x008, (I + 1) * NM / ND - I * NM / ND, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        pin_reads_between_mfmas<I + 1, NM, ND>();
+    }
+}
+
 __device__ __forceinline__ float split_load(const float* base, size_t row_floats, int n) {
     // value (hi + lo) of channel n of a split-NHWC pixel whose line starts at base + row_floats
     const _Float16* p = reinterpret_cast<const _Float16*>(base + row_floats) + (n >> 5) * 64 + (n & 31);

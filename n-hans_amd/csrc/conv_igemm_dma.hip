@@ -210,6 +210,47 @@ __global__ void __launch_bounds__(512) conv_igemm_dma(const ConvArgs a) {
                 }                                                                                  \
     }
 
+    // The same, half a chunk at a time (k-steps [H*KS/2, (H+1)*KS/2)): one half is read while the other
+    // is multiplied.  Per accumulator the products are added in the order of NH_MFMA_FRAGS (same bits);
+    // consecutive MFMAs go to different accumulators.
+    constexpr int KHD = KS / 2;
+#define NH_READ_HALF_D(H, ST)                                                                      \
+    {                                                                                              \
+        const float* Sb_ = smem + (ST) * STAGE;                                                    \
+        _Pragma("unroll") for (int s = (H) * KHD; s < ((H) + 1) * KHD; ++s) {                      \
+            _Pragma("unroll") for (int t = 0; t < TM; ++t) {                                       \
+                fa_hi[s][t] = *reinterpret_cast<const f32x4*>(Sb_ + aoff[t] + (((2 * s + g8) ^ rsw) * 4)); \
+                if constexpr (PREC == 1)                                                           \
+                    fa_lo[s][t] = *reinterpret_cast<const f32x4*>(Sb_ + aoff[t] + (((2 * s + g8 + 4) ^ rsw) * 4)); \
+            }                                                                                      \
+            _Pragma("unroll") for (int j = 0; j < TN; ++j) {                                       \
+                if constexpr (PREC == 1) {                                                         \
+                    fb_hi[s][j] = *reinterpret_cast<const f32x4*>(Sb_ + bcol + j * 1024 + s * 512);       \
+                    fb_lo[s][j] = *reinterpret_cast<const f32x4*>(Sb_ + bcol + j * 1024 + s * 512 + 256); \
+                } else {                                                                           \
+                    fb_hi[s][j] = *reinterpret_cast<const f32x4*>(Sb_ + bcol + j * 1024 + s * 256); \
+                }                                                                                  \
+            }                                                                                      \
+        }                                                                                          \
+    }
+#define NH_MFMA_HALF_D(H)                                                                          \
+    {                                                                                              \
+        _Pragma("unroll") for (int s = (H) * KHD; s < ((H) + 1) * KHD; ++s)                        \
+            _Pragma("unroll") for (int p = 0; p < (PREC == 1 ? 3 : 4); ++p)                        \
+                _Pragma("unroll") for (int t = 0; t < TM; ++t)                                     \
+                    _Pragma("unroll") for (int j = 0; j < TN; ++j) {                               \
+                        if constexpr (PREC == 1) {                                                 \
+                            const f16x8 a_ = __builtin_bit_cast(f16x8, p == 0 ? fa_lo[s][t] : fa_hi[s][t]); \
+                            const f16x8 b_ = __builtin_bit_cast(f16x8, p == 1 ? fb_lo[s][j] : fb_hi[s][j]); \
+                            acc[t][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b_, a_, acc[t][j], 0, 0, 0); \
+                        } else {                                                                   \
+                            acc[t][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb_hi[s][j][p], fa_hi[s][t][p], acc[t][j], 0, 0, 0); \
+                        }                                                                          \
+                    }                                                                              \
+    }
+    constexpr int NMD = KHD * TM * TN * (PREC == 1 ? 3 : 4);        // MFMAs per half
+    constexpr int NDD = KHD * (TM + TN) * (PREC == 1 ? 2 : 1);      // ds_read_b128 per half
+
     f32x16 acc[TM][TN];
 #pragma unroll
     for (int t = 0; t < TM; ++t)
@@ -305,6 +346,36 @@ __global__ void __launch_bounds__(512) conv_igemm_dma(const ConvArgs a) {
             st = st == 2 ? 0 : st + 1;
         }
         if (!grp_b) __builtin_amdgcn_s_barrier();
+    } else if (ABL == 0 && GRP == 0 && !(kDev && a.dbg)) {
+        // (every launch that is not a grouped-sum / split-K one: the strided convs and the head conv)
+        // Half-chunk register pipeline with the reads pinned between the MFMAs (as conv_igemm_halo.hip):
+        //   issue the DMA of chunk it+2 | MFMAs of half 0 of chunk it + reads of its half 1 | counted wait,
+        //   barrier: chunk it+1 has landed everywhere, nobody reads chunk it any more | MFMAs of half 1 +
+        //   reads of half 0 of chunk it+1.
+        int st = 0;
+        NH_READ_HALF_D(0, 0)
+        for (int it = 0; it < total; ++it) {
+            if (it + 2 < total) {
+                const int st2 = st >= 1 ? st - 1 : st + 2;             // (st + 2) % 3
+                NH_ISSUE(st2)                                           // chunk it+2 -> stage freed at it-1
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            NH_MFMA_HALF_D(0)
+            NH_READ_HALF_D(1, st)
+            pin_reads_between_mfmas<0, NMD, NDD>();
+            __builtin_amdgcn_sched_barrier(0);
+            if (it + 2 < total) wait_vmcnt<G>(); else wait_vmcnt<0>();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            st = st == 2 ? 0 : st + 1;
+            NH_MFMA_HALF_D(1)
+            NH_READ_HALF_D(0, st)                                       // (past the last chunk: a harmless read)
+            pin_reads_between_mfmas<0, NMD, NDD>();
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                  // the harmless read past the end has returned before the epilogue reuses the LDS
     } else {
         int st = 0;                                    // ring stage of chunk `it`
         long long ph0 = 0, ph1 = 0, ph2 = 0, ph3 = 0, tq = 0;          // dev tool: in-loop phase cycles

@@ -59,16 +59,6 @@ template <int HBM_> struct HaloShape {
     static constexpr int NAP = HR * 8 / (NPW * 64);          // activation DMA instructions per producer thread per image
 };
 
-// scheduling pattern of a consumer half: ND operand reads spread evenly between NM MFMAs
-// (sched_group_barrier masks: 0x008 MFMA, 0x100 DS read)
-template <int I, int NM, int ND> __device__ __forceinline__ void halo_pin_interleave() {
-    if constexpr (I < ND) {
-        __builtin_amdgcn_sched_group_barrier(0x008, (I + 1) * NM / ND - I * NM / ND, 0);
-        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-        halo_pin_interleave<I + 1, NM, ND>();
-    }
-}
-
 template <int N> __device__ __forceinline__ void halo_wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
@@ -369,7 +359,7 @@ __global__ void __launch_bounds__((NCW + NPW) * 64) conv_igemm_halo(const ConvAr
     constexpr int ND = KH_ * (TM + TN) * (PREC == 1 ? 2 : 1);       // ds_read_b128 per half
     static_assert(NM >= ND, "interleave pattern");
 #define NH_PIN_INTERLEAVE()                                                                        \
-    if constexpr (!(ABL & (16 | 32 | 128))) halo_pin_interleave<0, NM, ND>();
+    if constexpr (!(ABL & (16 | 32 | 128))) pin_reads_between_mfmas<0, NM, ND>();
     NH_READ_HALF(0, 0)
     int stC = 0;                                        // ring stage of tap `it`
     for (int it = 0; it < total; ++it) {
