@@ -77,7 +77,8 @@ int64_t nhans_num_frames(int64_t nsamples);
 int nhans_create(int model_kind, const void* folded_blob, size_t nbytes, int device_id, nhans_ctx** out);
 void nhans_destroy(nhans_ctx* ctx);
 
-/* Options: "frames_per_chunk" (mask-net frame windows per pass, default 1024),
+/* Options: "frames_per_chunk" (mask-net frame windows per pass, default 3776: 20 GB of workspace for batches
+ *           that large, chosen so that the launches fill whole waves of 256 workgroups),
  *          "contexts_per_chunk" (embedding-tower images per pass, default 64),
  *          "profile" (1: time every kernel launch with hipEvents on the launch stream),
  *          "precision" (0: exact f32 matrix-core path, default; 1: split-f16 x3 -- every operand is

@@ -103,7 +103,13 @@ struct nhans_ctx {
     size_t kscratch_bytes = (size_t)64 << 20;
     int* kcounter = nullptr;
     int kcounter_n = 1024;
-    int64_t frames_per_chunk = 1024;
+    // Frame windows per pass of the stack.  Every launch runs whole "waves" of one workgroup per CU and all
+    // workgroups of a launch take the same time, so a launch whose tile count is not a multiple of 256
+    // leaves CUs idle for a tile time at its end: 1,024 frames give resblock4 (130 pixels per frame, 256-pixel
+    // x 4 channel tiles) 8.1 waves = 9.7 % lost, 3.9 % over the whole stack.  3,776 = 59 x 64 frames minimise
+    // the FLOP-weighted loss (0.18 %) among the sizes whose largest tensor (3,776 x 35 x 201 x 64 elements)
+    // still fits the kernels' 32-bit element offsets; the three ping-pong buffers are then 20 GB of the 288.
+    int64_t frames_per_chunk = 3776;
     int contexts_per_chunk = 64;
     // pinned staging ring for the small host tables (offsets, block lists) copied per call
     char* pin = nullptr;

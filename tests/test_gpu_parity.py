@@ -230,7 +230,7 @@ def test_chunking_is_invisible(eng_d):
     a = eng_d.enhance([mix], [ca], [cb], want_mixed=False, taps=True)
     eng_d.set_option("frames_per_chunk", 37)
     b = eng_d.enhance([mix], [ca], [cb], want_mixed=False, taps=True)
-    eng_d.set_option("frames_per_chunk", 1024)
+    eng_d.set_option("frames_per_chunk", 3776)
     assert np.array_equal(a["logits"], b["logits"]) and np.array_equal(a["denoised_wav"][0], b["denoised_wav"][0])
 
 

@@ -1,5 +1,5 @@
 """GPU tests at BASELINE configuration scale (configs[2]: hundreds of clips, hundreds of
-1024-frame chunks, clips straddling chunk boundaries) and of the post-outputs / separator at 10 s.
+chunks of frame windows, clips straddling chunk boundaries) and of the post-outputs / separator at 10 s.
 Oracle runs of that size are out of reach, so the checks are: committed golden frames of a clip placed
 at several batch positions, bitwise equality with the single-clip run (batch, chunk and position
 invariance), finiteness of every output, and the STFT->iSTFT identity on sampled clips.
@@ -72,18 +72,18 @@ def test_ragged_batch_of_64_clips_across_chunk_boundaries(eng, prec):
             assert np.array_equal(lg, out["logits"][foff[0]:foff[1]])                   # position-invariant, bit for bit
             assert np.array_equal(out["denoised_wav"][pos], out["denoised_wav"][0])
         # sampled clips: the batch run == the clip on its own (other chunking too), bit for bit
-        eng.set_option("frames_per_chunk", 1024)
+        eng.set_option("frames_per_chunk", 1024)                      # (another chunking than the batch run)
         for i in (0, 1, 2, 17, 30, 32, 62):
             single = eng.enhance([mixes[i]], [cas[i]], [cbs[i]], want_mixed=True, taps=True)
             assert np.array_equal(single["logits"], out["logits"][foff[i]:foff[i + 1]]), i
             assert np.array_equal(single["denoised_wav"][0], out["denoised_wav"][i]), i
             assert np.array_equal(single["mixed_wav"][0], out["mixed_wav"][i]), i
     finally:
-        eng.set_option("frames_per_chunk", 1024)
+        eng.set_option("frames_per_chunk", 3776)
 
 
 def test_batch_of_256_ten_second_clips(eng):
-    """BASELINE configs[2] in one call: 256 x 10 s = 255,488 frame windows, 250 chunks of 1024.  32
+    """BASELINE configs[2] in one call: 256 x 10 s = 255,488 frame windows, 68 chunks of 3,776.  32
     distinct clips repeated 8 times, the golden clip among them: golden frames at three batch
     positions, every repetition bit-identical to the first, every sample finite, round trip intact."""
     eng.set_precision("f16x3")
@@ -104,7 +104,7 @@ def test_batch_of_256_ten_second_clips(eng):
     for pos in (0, 96, 224):                                       # golden clip = every 32nd
         assert float((lg[pos][fr] - gl).abs().max()) < 5 * LOGIT_TOL, pos
     first = lg[:32]
-    for rep in range(1, 8):                                        # chunk phase differs per repetition: 998*32 % 1024 != 0
+    for rep in range(1, 8):                                        # chunk phase differs per repetition: 998*32 % 3776 != 0
         assert torch.equal(lg[32 * rep:32 * rep + 32], first), rep
         assert torch.equal(den[32 * rep:32 * rep + 32], den[:32]), rep
     # single-clip run of three of them == their rows in the batch
@@ -139,7 +139,7 @@ def test_separator_ten_second_clip(eng_sep, prec):
     try:
         b = eng_sep.enhance([mix] * 4, [ca] * 4, [cb] * 4, want_mixed=False, taps=True)
     finally:
-        eng_sep.set_option("frames_per_chunk", 1024)
+        eng_sep.set_option("frames_per_chunk", 3776)
     for i in range(4):
         assert np.array_equal(b["logits"][998 * i:998 * (i + 1)], out["logits"])
         assert np.array_equal(b["denoised_wav"][i], out["denoised_wav"][0])
