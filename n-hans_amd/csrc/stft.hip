@@ -134,28 +134,20 @@ __global__ void __launch_bounds__(256) stft_features_kernel(
             for (int n2 = 0; n2 < 20; ++n2) row[n2] = tf[n2];
             fft400_pass2<false>(row, X);
         }
-        __syncthreads();
-        if (active) {
-            // bins 0..200 only: k = q + 20*k2 with k2 <= 9, plus k = 200 (q = 0, k2 = 10)
-            cplx* sp = tw_wave + j * kBins;          // [3][201] spectrum rows, aliasing the transpose
+        __syncthreads();                            // every lane has its row: the transpose buffer is free again
+        if (active && f0 + lf0 + j < T) {
+            // bins 0..200 only: k = q + 20*k2 with k2 <= 9, plus k = 200 (q = 0, k2 = 10).  Straight from the
+            // registers of pass 2: for a fixed k2 the 20 lanes of a frame write 20 consecutive floats.
+            const int64_t o = (fr_beg + f0 + lf0 + j) * kBins + q;
 #pragma unroll
-            for (int k2 = 0; k2 < 10; ++k2) sp[q + 20 * k2] = X[k2];
-            if (q == 0) sp[200] = X[10];
-        }
-        __syncthreads();
-        {
-            const int fglob0 = f0 + lf0;             // first frame of this wave (clip-relative)
-            for (int idx = lane; idx < kFpw * kBins; idx += 64) {
-                const int jj = idx / kBins;
-                if (fglob0 + jj >= T) break;
-                const cplx v = tw_wave[idx];
+            for (int k2 = 0; k2 < 11; ++k2) {
+                if (k2 == 10 && q != 0) break;
+                const cplx v = X[k2];
                 const float mag = __builtin_amdgcn_sqrtf(v.x * v.x + v.y * v.y);
-                const int64_t o = (fr_beg + fglob0) * kBins + idx;
-                logmag[o] = fast_log(mag + 1e-5f);
-                if (phase) phase[o] = fast_atan2(v.y, v.x);
+                logmag[o + 20 * k2] = fast_log(mag + 1e-5f);
+                if (phase) phase[o + 20 * k2] = fast_atan2(v.y, v.x);
             }
         }
-        __syncthreads();
     }
   }
 }
