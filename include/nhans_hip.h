@@ -91,7 +91,10 @@ void nhans_destroy(nhans_ctx* ctx);
  *          "epilogue_wide" (1, default: split-f16 epilogues move 8 channels = 16-byte pieces per thread;
  *           0: 4 channels -- identical bits, kept for A/B),
  *          "consumer_interleave" (1, default: the MFMA waves of the halo kernels issue their LDS operand
- *           reads between their MFMAs; 0: read block then MFMA block -- identical bits, kept for A/B).
+ *           reads between their MFMAs; 0: read block then MFMA block -- identical bits, kept for A/B),
+ *          "persistent_tiles" (0, default; 1: launches with >= 2 tiles per CU run the halo kernels as persistent
+ *           workgroups whose DMA pipeline runs on across tile boundaries -- identical bits, measured 2-3 %
+ *           slower, kept so that the measurement can be repeated).
  * (A `make DEV=1` build adds "debug_cycles_ptr" and the NHANS_ABLATE / NHANS_HALO2D environment
  * switches used by tools/; the default build has no developer hooks and reads no environment.)
  * Besides the workspace a context holds 64 MB of split-K scratch for the few launches that are

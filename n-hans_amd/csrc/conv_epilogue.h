@@ -33,6 +33,17 @@ template <int I, int NM, int ND> __device__ __forceinline__ void pin_reads_betwe
     }
 }
 
+// The epilogue's arithmetic, spelled out so that every kernel variant rounds alike (whether the compiler
+// contracts a*b+c into an fma depends on the surrounding code; a layer must give the same bits whichever
+// variant its launch size selects):  v = fma(acc, ws, cb) + tf;  v = fma(idw, residual, v).
+__device__ __forceinline__ f32x4 fma4(f32x4 a, f32x4 b, f32x4 c) {
+    return f32x4{__builtin_fmaf(a.x, b.x, c.x), __builtin_fmaf(a.y, b.y, c.y), __builtin_fmaf(a.z, b.z, c.z),
+                 __builtin_fmaf(a.w, b.w, c.w)};
+}
+__device__ __forceinline__ f32x4 epi_combine(f32x4 acc, f32x4 ws, f32x4 cb, f32x4 tf, f32x4 idw, f32x4 res) {
+    return fma4(idw, res, fma4(acc, ws, cb) + tf);
+}
+
 __device__ __forceinline__ float split_load(const float* base, size_t row_floats, int n) {
     // value (hi + lo) of channel n of a split-NHWC pixel whose line starts at base + row_floats
     const _Float16* p = reinterpret_cast<const _Float16*>(base + row_floats) + (n >> 5) * 64 + (n & 31);
@@ -104,7 +115,7 @@ __device__ __forceinline__ void conv_epilogue_sweep(const ConvArgs& a, const flo
                 const float sv = a.id[ri.w];
                 idv = f32x4{sv, sv, sv, sv};
             }
-            const f32x4 y = ((av * wsv + c) + t) + idwv * idv;
+            const f32x4 y = epi_combine(av, wsv, c, t, idwv, idv);
             yv[u] = f32x4{fmaxf(y.x, lo_clamp), fmaxf(y.y, lo_clamp), fmaxf(y.z, lo_clamp), fmaxf(y.w, lo_clamp)};
         }
 #pragma unroll
@@ -215,8 +226,8 @@ __device__ __forceinline__ void conv_epilogue_sweep8(const ConvArgs& a, const fl
                 i1 = i0;
             }
             const f32x4 c0 = HOIST ? hc0 : r[u].c0, c1 = HOIST ? hc1 : r[u].c1;
-            const f32x4 r0 = ((av0 * ws0 + c0) + r[u].t0) + iw0 * i0;
-            const f32x4 r1 = ((av1 * ws1 + c1) + r[u].t1) + iw1 * i1;
+            const f32x4 r0 = epi_combine(av0, ws0, c0, r[u].t0, iw0, i0);
+            const f32x4 r1 = epi_combine(av1, ws1, c1, r[u].t1, iw1, i1);
             if (r[u].m >= 0) {
                 f16x8 h, l;
 #pragma unroll
@@ -344,12 +355,11 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[T
                 const int ne = n + e;
                 if (ne >= a.Nreal) continue;
                 float x = ct[p * LDC + c4 * 4 + e];
-                if constexpr (PREC == 1) x *= a.ws[ne];
-                x = (x + cbp[ri.x + ne]) + tfp[(ri.y + ne) * f_tf];
+                x = __builtin_fmaf(x, PREC == 1 ? a.ws[ne] : 1.f, cbp[ri.x + ne]) + tfp[(ri.y + ne) * f_tf];
                 float y = x;
                 if (a.id_mode == 1)
-                    y += a.idw[ne] * (id_split ? split_load(a.id, (size_t)m * a.id_ld, ne) : a.id[(size_t)m * a.id_ld + ne]);
-                else if (a.id_mode == 2) y += a.idw[ne] * idsv;
+                    y = __builtin_fmaf(a.idw[ne], id_split ? split_load(a.id, (size_t)m * a.id_ld, ne) : a.id[(size_t)m * a.id_ld + ne], y);
+                else if (a.id_mode == 2) y = __builtin_fmaf(a.idw[ne], idsv, y);
                 if (a.relu) y = fmaxf(y, 0.f);
                 if (a.aux) a.aux[(size_t)m * a.aux_ld + ne] = x;
                 a.out[(size_t)m * a.ldo + ne] = y;

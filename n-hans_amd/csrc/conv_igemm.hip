@@ -345,13 +345,14 @@ double launch_conv_igemm(const ConvArgs& a0, hipStream_t s, const char** kernel)
         // launch size: the choice must not depend on the batch)
         const bool halo_ok = a.variant >= 2 && a.kgroup >= 0;
         if (halo_ok && !wide && a.variant == 2 && conv_igemm_halo_eligible(a)) {
-            launch_conv_igemm_halo(a, s);            // the 64-channel stride-1 convs: 512-pixel tiles
-            name = "conv_igemm_halo<64,512>";
+            // the 64-channel stride-1 convs: 512-pixel tiles
+            if (launch_conv_igemm_halo_persist(a, s)) name = "conv_igemm_halo_persist<64,512>";
+            else { launch_conv_igemm_halo(a, s); name = "conv_igemm_halo<64,512>"; }
         } else if (halo_ok && launch_conv_igemm_halo2d(a, s)) {
             name = "conv_igemm_halo2d<64>";          // (variant 3) 2-D 256-pixel tiles for the same layers
         } else if (halo_ok && (a.halo64_tile512 = 0, conv_igemm_halo_eligible(a))) {
-            launch_conv_igemm_halo(a, s);
-            name = wide ? "conv_igemm_halo<128>" : "conv_igemm_halo<64>";
+            if (wide && launch_conv_igemm_halo_persist(a, s)) name = "conv_igemm_halo_persist<128>";
+            else { launch_conv_igemm_halo(a, s); name = wide ? "conv_igemm_halo<128>" : "conv_igemm_halo<64>"; }
         } else {
             launch_conv_igemm_dma(a, s);
             name = a.kgroup < 0 ? (wide ? "conv_igemm_dma<128,grouped>" : "conv_igemm_dma<64,grouped>")

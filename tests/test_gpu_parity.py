@@ -177,6 +177,30 @@ def test_mask_net_is_bitwise_reproducible(eng_d):
         assert torch.equal(first, again)
 
 
+@pytest.mark.parametrize("option, values", [("persistent_tiles", (1, 0)), ("consumer_interleave", (0, 1)),
+                                            ("epilogue_wide", (0, 1)), ("conv_variant", (3, -1))])
+def test_speed_knobs_do_not_change_a_bit(_eng_d, option, values):
+    """The A/B options of the C ABI select other instruction orders / tile walks of the same arithmetic:
+    a 10 s clip (thousands of tiles per layer, so that the persistent kernels really run) must give
+    identical logits whichever way they are set.  (conv_variant 3 = 2-D tiles for the 64-channel convs sums in
+    another order: within tolerance, not bitwise.)"""
+    _eng_d.set_precision("f16x3")
+    g = load_case("case_synth10s")
+    lm = torch.from_numpy(g["logmag"]).cuda()
+    ea = torch.from_numpy(g["emb_a"][None]).cuda()
+    eb = torch.from_numpy(g["emb_b"][None]).cuda()
+    ref = _eng_d.mask_net(lm, [0, 998], ea, eb)[0].clone()
+    try:
+        _eng_d.set_option(option, values[0])
+        got = _eng_d.mask_net(lm, [0, 998], ea, eb)[0]
+        if option == "conv_variant":
+            assert float((got - ref).abs().max()) < LOGIT_TOL
+        else:
+            assert torch.equal(got, ref), option
+    finally:
+        _eng_d.set_option(option, values[1])
+
+
 def test_separator_model(eng_s):
     g = load_case("case_separator")
     mix = apply.trim_to_frames(apply.normalise(synth.mixture(3, 2.0)))
