@@ -6,20 +6,20 @@
 //   istft_ola_kernel     : exp(logmag) * e^{j phase} -> tf.signal.inverse_stft(400, 160, 400,
 //                          window_fn=inverse_stft_window_fn(160, hann periodic))   (SN/apply.py:189-204)
 //
-// Both are HBM-bound (2,248 algorithmic bytes per frame).  A workgroup of 4 wavefronts handles a
-// run of consecutive frames of one clip: the sample span (400 + 160*(F-1) samples) is loaded once,
-// coalesced, into LDS, so each input sample crosses HBM once although it belongs to 2.5 frames.
-// The workgroups are persistent (two per CU, the LDS they need allows no more) and walk the list of
-// frame runs; the samples of the NEXT run are fetched into registers before the current run is
-// transformed, so that HBM requests are in flight all the time -- with one run per workgroup the
-// kernel spent its time in load -> barrier -> compute -> store round trips (ablating the transform or
-// the log/atan2 changed its 0.57 ms at 256 clips by 10 %).
-// The 400-point transform is 20 x 20 (fft400.h): every lane computes one 20-point DFT in
-// registers, a wavefront carries 3 frames (60 of 64 lanes busy), and the 20x20 transpose between
-// the two passes goes through LDS rows padded to 21 complex values.  log/atan2 (and exp/sincos
-// on the way back) are spread over all 64 lanes and written as contiguous 201-float rows.
-// Overlap-add is in gather form: each output sample is summed by one thread from its <= 3
-// windowed frames in ascending frame order -- no atomics, bitwise deterministic.
+// Both are HBM-bound by their algorithmic bytes (2,248 per frame) and VALU-instruction-bound in practice.
+// The 400-point transform is 20 x 20 (fft400.h): every lane computes one 20-point DFT in registers, and the
+// 20x20 transpose between the two passes goes through a wavefront-private LDS area (rows padded to 21 complex
+// values), synchronised at wavefront level only.  TWO REAL FRAMES SHARE ONE COMPLEX TRANSFORM (z = a + i b), so
+// a wavefront carries 3 transforms = 6 frames (60 of 64 lanes busy) and a workgroup 24 frames per pass.
+// Workgroups are persistent and walk the list of 24-frame runs of the batch.
+//   STFT: a lane's 2 x 20 samples come straight from global memory (20 lanes read 80 contiguous bytes; the overlap
+//   of neighbouring frames is served by the caches); bins are untangled (A = (Z[k] + conj Z[400-k]) / 2, ...) and
+//   turned into log-magnitude / phase by all 64 lanes, 201 contiguous floats per frame and array.
+//   iSTFT: the next run's log-magnitudes and phases are fetched into registers before the current run is
+//   transformed; Z = A + iB is built for all 400 bins in LDS; the windowed frames land in an LDS buffer that
+//   aliases the transform areas; overlap-add is in gather form (each output sample summed by one thread from
+//   its <= 3 frames in ascending order: no atomics, bitwise deterministic).
+// log/atan2/exp/sincos run on the hardware transcendental units (below).
 #include "nhans_kernels.h"
 #include "fft400.h"
 
@@ -65,7 +65,6 @@ __device__ __forceinline__ void fast_sincos(float a, float* sn, float* cs) {   /
     *cs = __builtin_amdgcn_cosf(rev);
 }
 
-constexpr int kPersistentGrid = 256 * 2; // two resident workgroups per CU (61 KB / 45 KB of LDS each)
 
 // A wavefront's transpose / spectrum area is private to it: its lanes exchange data through it with no
 // workgroup barrier, only "my LDS traffic has completed" (lanes of a wave run in lockstep).
@@ -183,131 +182,144 @@ void launch_stft(const float* wav, ClipTable t, const int* block_clip, const int
 }
 
 // ---------------------------------------------------------------------------------------------
+// Inverse: two frames per complex transform as well.  With A, B the (Hermitian) spectra of frames a and b,
+// Z = A + iB has the inverse transform z = a + i b: real part = frame a, imaginary part = frame b.  The DC and
+// Nyquist bins enter with their imaginary parts dropped, which is what a real inverse FFT does with them.
 __global__ void __launch_bounds__(256) istft_ola_kernel(
     const float* __restrict__ logmag, const float* __restrict__ phase, ClipTable tab,
     const int* __restrict__ block_clip, const int* __restrict__ block_h0, int nblocks, const cplx* __restrict__ tw400g,
     const float* __restrict__ wsyng, float* __restrict__ wav_out) {
     constexpr int HB = kIstftHopsPerBlock;          // output hops per block
     constexpr int F = HB + 2;                        // frames needed: h0-2 .. h0+HB-1
+    static_assert(F == 4 * kFpw * 2, "24 frames = 4 waves x 3 transforms x 2 frames");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     cplx* tw = reinterpret_cast<cplx*>(smem_raw);                 // 400
-    cplx* tbuf = tw + 400;                                        // 4*3*420
-    cplx* sbuf = tbuf + 4 * kFpw * kTFrame;                       // 4*3*201
-    float* wsyn = reinterpret_cast<float*>(sbuf + 4 * kFpw * kBins);   // 400
-    float* y = wsyn + kWin;                                       // F*400
+    float* wsyn = reinterpret_cast<float*>(tw + 400);             // 400
+    cplx* area = reinterpret_cast<cplx*>(wsyn + kWin);            // per wave 3 x 420: spectra Z, then transpose rows
+    float* y = reinterpret_cast<float*>(area);                    // [F][400] windowed frames, aliasing the areas
+    static_assert((size_t)F * kWin * sizeof(float) <= (size_t)4 * kFpw * kTFrame * sizeof(cplx), "y fits the areas");
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    constexpr int NPASS = F / (4 * kFpw);
-    constexpr int NIN = (kFpw * kBins + 63) / 64;    // spectrum values per lane of one wave-pass (3 frames x 201 bins)
-    // Persistent workgroups (as stft_features_kernel): the log-magnitudes and phases of the NEXT pass are in
-    // flight while the current one is transformed.
-    float plm[NIN], pph[NIN];
-    unsigned pvalid = 0;
-    auto fetch = [&](int blk, int p) {
+    const int j = lane / 20, q = lane - j * 20;
+    const bool active = lane < 60;
+    cplx* a_wave = area + wave * kFpw * kTFrame;
+    const int lf0 = wave * kFpw * 2;                 // first local frame of this wave; clip frame = h0 - 2 + lf
+
+    constexpr int NIN = (kFpw * kBins + 63) / 64;    // (transform, bin) items per lane
+    float la[NIN], pa[NIN], lb[NIN], pb[NIN];        // log-magnitude / phase of frames a and b of the NEXT run
+    unsigned va = 0, vb = 0;
+    auto fetch = [&](int blk) {
         const int c = block_clip[blk];
-        const int64_t fb = tab.frame_off[c];
-        const int Tc = (int)(tab.frame_off[c + 1] - fb);
-        const int fr0 = block_h0[blk] - 2 + p * 4 * kFpw + wave * kFpw;
-        pvalid = 0;
+        const int64_t fb_ = tab.frame_off[c];
+        const int Tc = (int)(tab.frame_off[c + 1] - fb_);
+        const int fr0 = block_h0[blk] - 2 + lf0;
+        va = 0; vb = 0;
 #pragma unroll
         for (int u = 0; u < NIN; ++u) {
             const int idx = u * 64 + lane;
-            const int jj = idx / kBins;
-            const int fr = fr0 + jj;
-            const bool ok = idx < kFpw * kBins && fr >= 0 && fr < Tc;
-            const int64_t o = ok ? (fb + fr) * kBins + (idx - jj * kBins) : 0;
-            plm[u] = logmag[o];
-            pph[u] = phase[o];
-            pvalid |= ok ? 1u << u : 0u;
+            const int tr = idx / kBins, k = idx - tr * kBins;
+            const int fa = fr0 + 2 * tr;
+            const bool oka = idx < kFpw * kBins && fa >= 0 && fa < Tc;
+            const bool okb = idx < kFpw * kBins && fa + 1 >= 0 && fa + 1 < Tc;
+            const int64_t oa = oka ? (fb_ + fa) * kBins + k : 0, ob = okb ? (fb_ + fa + 1) * kBins + k : 0;
+            la[u] = logmag[oa]; pa[u] = phase[oa];
+            lb[u] = logmag[ob]; pb[u] = phase[ob];
+            va |= oka ? 1u << u : 0u;
+            vb |= okb ? 1u << u : 0u;
         }
     };
 
     for (int i = tid; i < 400; i += 256) { tw[i] = tw400g[i]; wsyn[i] = wsyng[i]; }
-    fetch(blockIdx.x, 0);
+    fetch(blockIdx.x);
     __syncthreads();
 
-    const int j = lane / 20, q = lane - j * 20;
-    const bool active = lane < 60;
-    cplx* t_wave = tbuf + wave * kFpw * kTFrame;
-    cplx* s_wave = sbuf + wave * kFpw * kBins;
-
 #pragma unroll 1
-  for (int blk = blockIdx.x; blk < nblocks; blk += gridDim.x) {
-    const int clip = block_clip[blk], h0 = block_h0[blk];
-    const int64_t fr_beg = tab.frame_off[clip];
-    const int T = (int)(tab.frame_off[clip + 1] - fr_beg);
-    const int64_t nout = (int64_t)(T - 1) * kHop + kWin;
-#pragma unroll 1
-    for (int p = 0; p < NPASS; ++p) {
-        const int lf0 = p * 4 * kFpw + wave * kFpw;          // local frame index; clip frame = h0-2+lf
-        // spectrum: |S| = exp(logmag), S = |S| e^{j phase}; frames outside [0,T) contribute zero
+    for (int blk = blockIdx.x; blk < nblocks; blk += gridDim.x) {
+        const int clip = block_clip[blk], h0 = block_h0[blk];
+        const int64_t fr_beg = tab.frame_off[clip];
+        const int T = (int)(tab.frame_off[clip + 1] - fr_beg);
+        const int64_t nout = (int64_t)(T - 1) * kHop + kWin;
+        // Z = A + iB over all 400 bins from the 201 given ones (frames outside [0, T) contribute zero)
 #pragma unroll
         for (int u = 0; u < NIN; ++u) {
             const int idx = u * 64 + lane;
-            const float mag = fast_exp(plm[u]);
+            const int tr = idx / kBins, k = idx - tr * kBins;
             float sn, cs;
-            fast_sincos(pph[u], &sn, &cs);
-            const bool ok = (pvalid >> u) & 1u;
-            if (idx < kFpw * kBins) s_wave[idx] = ok ? cmake(mag * cs, mag * sn) : cmake(0.f, 0.f);
-        }
-        if (p + 1 < NPASS) fetch(blk, p + 1);
-        else if (blk + (int)gridDim.x < nblocks) fetch(blk + gridDim.x, 0);
-        __syncthreads();
-        if (active) {
-            // pass 1 over the Hermitian-extended spectrum: lane = b, inputs X[20a + b]
-            cplx col[20], yv[20];
-            const cplx* sp = s_wave + j * kBins;
-#pragma unroll
-            for (int a = 0; a < 20; ++a) {
-                const int k = 20 * a + q;
-                col[a] = (k <= 200) ? sp[k] : cconj(sp[400 - k]);
+            fast_sincos(pa[u], &sn, &cs);
+            const float ma = ((va >> u) & 1u) ? fast_exp(la[u]) : 0.f;
+            float are = ma * cs, aim = ma * sn;
+            fast_sincos(pb[u], &sn, &cs);
+            const float mb = ((vb >> u) & 1u) ? fast_exp(lb[u]) : 0.f;
+            float bre = mb * cs, bim = mb * sn;
+            const bool edge = k == 0 || k == 200;
+            if (edge) { aim = 0.f; bim = 0.f; }
+            if (idx < kFpw * kBins) {
+                cplx* z = a_wave + tr * 400;
+                z[k] = cmake(are - bim, aim + bre);
+                if (!edge) z[400 - k] = cmake(are + bim, bre - aim);
             }
+        }
+        if (blk + (int)gridDim.x < nblocks) fetch(blk + gridDim.x);
+        wave_lds_sync();
+        cplx col[20];
+        if (active) {
+            const cplx* z = a_wave + j * 400;
+#pragma unroll
+            for (int a = 0; a < 20; ++a) col[a] = z[20 * a + q];
+        }
+        wave_lds_sync();                             // every lane holds its column: the area becomes the transpose buffer
+        if (active) {
+            cplx yv[20];
             fft400_pass1<true>(col, q, tw, yv);
-            cplx* tf = t_wave + j * kTFrame;
+            cplx* tf = a_wave + j * kTFrame;
 #pragma unroll
             for (int c1 = 0; c1 < 20; ++c1) tf[c1 * kTRow + q] = yv[c1];
         }
-        __syncthreads();
+        wave_lds_sync();
+        cplx x[20];
         if (active) {
-            cplx row[20], x[20];
-            const cplx* tf = t_wave + j * kTFrame + q * kTRow;
+            cplx row[20];
+            const cplx* tf = a_wave + j * kTFrame + q * kTRow;
 #pragma unroll
             for (int b = 0; b < 20; ++b) row[b] = tf[b];
             fft400_pass2<true>(row, x);
-            float* yf = y + (lf0 + j) * kWin;
+        }
+        __syncthreads();                             // every wave is through with its area: it becomes y
+        if (active) {
+            float* ya = y + (lf0 + 2 * j) * kWin;
 #pragma unroll
             for (int c2 = 0; c2 < 20; ++c2) {
                 const int n = q + 20 * c2;
-                yf[n] = x[c2].x * (1.0f / 400.0f) * wsyn[n];     // real part of the inverse transform
+                const float w = (1.0f / 400.0f) * wsyn[n];
+                ya[n] = x[c2].x * w;                 // real part: frame a
+                ya[kWin + n] = x[c2].y * w;          // imaginary part: frame b
             }
         }
         __syncthreads();
+        // gather-form overlap-add: sample i of hop u sums frames u-2, u-1, u (ascending)
+        const int64_t obase = tab.out_off[clip];
+        for (int i = tid; i < HB * kHop; i += 256) {
+            const int hl = i / kHop, r = i - hl * kHop;
+            const int64_t pos = (int64_t)(h0 + hl) * kHop + r;
+            if (pos >= nout) break;
+            float acc = 0.f;
+            if (r < kWin - 2 * kHop) acc = y[hl * kWin + 2 * kHop + r];
+            acc += y[(hl + 1) * kWin + kHop + r];
+            acc += y[(hl + 2) * kWin + r];
+            wav_out[obase + pos] = acc;
+        }
+        __syncthreads();                             // y has been read: the areas may be rewritten
     }
-
-    // gather-form overlap-add: sample i of hop u sums frames u-2, u-1, u (ascending)
-    const int64_t obase = tab.out_off[clip];
-    for (int i = tid; i < HB * kHop; i += 256) {
-        const int hl = i / kHop, r = i - hl * kHop;
-        const int64_t pos = (int64_t)(h0 + hl) * kHop + r;
-        if (pos >= nout) break;
-        float acc = 0.f;
-        if (r < kWin - 2 * kHop) acc = y[hl * kWin + 2 * kHop + r];
-        acc += y[(hl + 1) * kWin + kHop + r];
-        acc += y[(hl + 2) * kWin + r];
-        wav_out[obase + pos] = acc;
-    }
-  }
 }
 
 void launch_istft(const float* logmag, const float* phase, ClipTable t, const int* block_clip,
                   const int* block_h0, int nblocks, const float* tw400, const float* wsyn, float* wav_out,
                   hipStream_t s) {
     if (nblocks <= 0) return;
-    constexpr size_t lds = (400 + 4 * kFpw * kTFrame + 4 * kFpw * kBins) * sizeof(cplx) +
-                           (kWin + (kIstftHopsPerBlock + 2) * kWin) * sizeof(float);
+    constexpr size_t lds = (400 + 4 * kFpw * kTFrame) * sizeof(cplx) + kWin * sizeof(float);     // 45 KB
     static unsigned long long attr_devices = 0;
     set_max_dynamic_lds(reinterpret_cast<const void*>(&istft_ola_kernel), lds, &attr_devices, "istft_ola");
-    const int grid = nblocks < kPersistentGrid ? nblocks : kPersistentGrid;
+    const int grid = nblocks < 256 * 3 ? nblocks : 256 * 3;     // three resident workgroups per CU (LDS), two by registers
     NHANS_LAUNCH("istft_ola", istft_ola_kernel, dim3(grid), dim3(256), lds, s, logmag, phase, t, block_clip,
                  block_h0, nblocks, reinterpret_cast<const cplx*>(tw400), wsyn, wav_out);
 }
