@@ -65,3 +65,69 @@ def test_two_rank_gather_reassembles_batch():
     for p in procs:
         p.join(timeout=60)
     assert res == [(0, True), (1, True)]
+
+
+# ------------------------------------------------------------------------------ the product entry point, 2 ranks on CPU
+class _FakeEngine:
+    """Stands in for engine.Engine on the CPU box: recognisable waveforms, records what each rank was given."""
+    device = torch.device("cpu")
+
+    def __init__(self):
+        self.calls = []
+
+    def enhance(self, mixes, ca, cb, want_mixed=True, taps=False):
+        self.calls.append(len(mixes))
+        return {"denoised_wav": [m * np.float32(0.5) + a[:1] for m, a in zip(mixes, cb)], "mixed_wav": [m.copy() for m in mixes]}
+
+
+def _cli_worker(rank, world, port, argv, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK="0", NHANS_DIST_BACKEND="gloo")
+    from nhans_amd import apply
+    fake = _FakeEngine()
+    apply.set_engine("denoiser", fake)
+    apply.main(argv)
+    dist.barrier()
+    dist.destroy_process_group()
+    q.put((rank, fake.calls))
+
+
+def test_cli_directory_mode_shards_clips_over_two_ranks(tmp_path):
+    """`nhans_denoiser --input <dir>` under WORLD_SIZE=2: 5 clips -> blocks of 3 and 2, ONE engine call per rank,
+    one all-gather, rank 0 writes every file -- identical to what a single rank writes."""
+    from scipy.io import wavfile
+    from nhans_amd import apply, synth
+    ind, negd = tmp_path / "in", tmp_path / "neg"
+    ind.mkdir()
+    negd.mkdir()
+    names = ["c%d.wav" % i for i in range(5)]
+    for i, n in enumerate(names):
+        wavfile.write(str(ind / n), 16000, synth.mixture(70 + i, 0.05 + 0.03 * i))
+        wavfile.write(str(negd / n), 16000, synth.noise_context(70 + i, 1.0))
+    common = ["--input", str(ind), "--neg", str(negd), "--pos", str(tmp_path / "Silent.wav"), "--weights", "synthetic"]
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_cli_worker, args=(r, 2, port, common + ["--output", str(tmp_path / "out2")], q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=180) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+    assert res == [(0, [3]), (1, [2])]                       # contiguous blocks, one batched call per rank
+    fake = _FakeEngine()
+    apply.set_engine("denoiser", fake)
+    try:
+        for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+            os.environ.pop(k, None)
+        apply.main(common + ["--output", str(tmp_path / "out1")])
+    finally:
+        apply._engines.pop("denoiser", None)
+    assert fake.calls == [5]
+    files = sorted(os.listdir(str(tmp_path / "out1")))
+    assert files == sorted(os.listdir(str(tmp_path / "out2"))) and len(files) == 20
+    for f in files:
+        assert open(str(tmp_path / "out1" / f), "rb").read() == open(str(tmp_path / "out2" / f), "rb").read(), f
