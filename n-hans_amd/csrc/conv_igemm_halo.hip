@@ -491,7 +491,7 @@ void launch_conv_igemm_halo(const ConvArgs& a0, hipStream_t s) {
     if (a.prec == 1 && a.dbg) {     // cycle stamps, optionally of an ablated loop
 #define NH_DBG_CASE(V) case V: if (wide) launch_halo_t<128, 1, 256, 1, V>(a, s); else launch_halo_t<64, 1, 256, 1, V>(a, s); break;
         switch (abl) {
-            NH_DBG_CASE(10) NH_DBG_CASE(16) NH_DBG_CASE(32) NH_DBG_CASE(48) NH_DBG_CASE(128)
+            NH_DBG_CASE(1) NH_DBG_CASE(2) NH_DBG_CASE(4) NH_DBG_CASE(5) NH_DBG_CASE(8) NH_DBG_CASE(10) NH_DBG_CASE(16) NH_DBG_CASE(32) NH_DBG_CASE(48) NH_DBG_CASE(128)
             default: if (wide) launch_halo_t<128, 1, 256, 1>(a, s); else launch_halo_t<64, 1, 256, 1>(a, s);
         }
 #undef NH_DBG_CASE
