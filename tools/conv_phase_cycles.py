@@ -1,5 +1,6 @@
 """Dev tool: per-workgroup cycle breakdown (prologue / K loop / epilogue) of the LDS-DMA conv
-kernel for one layer, from s_memtime stamps written by the kernel (option debug_cycles_ptr).
+kernel for one layer, from s_memtime stamps written by the kernel (option debug_cycles_ptr; needs a developer build of the library:
+`make -C n-hans_amd/csrc clean && make -C n-hans_amd/csrc DEV=1`; NHANS_ABLATE=<mask> selects a timing ablation).
     NHANS_CONV_VARIANT=1 python tools/conv_phase_cycles.py [block 0..7] [frames]"""
 import os
 import sys

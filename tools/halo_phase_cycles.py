@@ -1,5 +1,6 @@
 """Dev tool: where the K loop of the halo conv kernel (conv_igemm_halo.hip) spends its cycles, from
-s_memtime stamps of waves 0 and 7 of every workgroup (option debug_cycles_ptr):
+s_memtime stamps of waves 0 and 7 of every workgroup (option debug_cycles_ptr; needs a developer build of the library:
+`make -C n-hans_amd/csrc clean && make -C n-hans_amd/csrc DEV=1`; NHANS_ABLATE=<mask> selects a timing ablation):
     python tools/halo_phase_cycles.py [block 0..7] [frames]"""
 import os
 import sys
