@@ -32,6 +32,16 @@ def main():
     run = lambda: eng.enhance_device(mix_t, mix_off, ca_t, ca_off, cb_t, cb_off)
     run()
     torch.cuda.synchronize()
+    # the knob must not change a bit of the result
+    outs = []
+    for v in a.variants:
+        eng.set_option(a.option, v)
+        outs.append(run()["denoised_wav"].clone())
+    torch.cuda.synchronize()
+    for v, o in zip(a.variants[1:], outs[1:]):
+        print("variant %d vs %d: bit-identical = %s (max |diff| %.3g)" % (v, a.variants[0], bool(torch.equal(o, outs[0])),
+                                                                       float((o - outs[0]).abs().max())))
+    del outs
     eng.set_option("profile", 1)
     res = {v: [] for v in a.variants}
     for r in range(a.rounds):
