@@ -32,6 +32,7 @@ from nhans_amd.apply import normalise, trim_to_frames  # noqa: E402
 
 F32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 F16_MFMA_PEAK_TFLOPS = 2500.0     # dense f16 MFMA peak; the split mode executes 3 products per MAC
+F16_MFMA_AT_POWER_CAP_TFLOPS = 1660.0   # measured: register-only f16 MFMA loop, random operands, 1,400 W cap (profiles/r02)
 HBM_PEAK_GBS = 8000.0             # spec; 6,290 GB/s is what a float4 copy achieves (same guide)
 HBM_ACHIEVABLE_GBS = 6290.0
 PMC_SUMMARY = os.path.join("profiles", "r02", "pmc_summary_bench_256clips.json")
@@ -49,6 +50,8 @@ def parse():
     p.add_argument("--kind", default="denoiser", choices=["denoiser", "separator"])
     p.add_argument("--frames-per-chunk", type=int, default=0)
     p.add_argument("--precision", default="f16x3", choices=["f32", "f16x3"])
+    p.add_argument("--option", action="append", default=[], metavar="KEY=VALUE",
+                   help="nhans_set_option knob for an A/B run (e.g. quad_workgroups=1); recorded in config")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-kernel-pass", action="store_true", help="skip the extra profiled pass (rocprofv3 runs)")
     p.add_argument("--cpu-frames", type=int, default=32, help="frames of the CPU baseline sample")
@@ -107,6 +110,61 @@ def cpu_baseline(W, kind, mix, ca, cb, frames, threads):
     return res
 
 
+class DeviceSampler:
+    """Shader clock and socket power of one GPU over the timed region, read from the amdgpu hwmon files in sysfs
+    by a thread of this process (no child process): the chip runs at its socket power cap under this workload, so
+    the sustained clock -- not the datasheet 2.4 GHz -- is what a matrix-pipe rate should be read against."""
+
+    def __init__(self, device_index, period=0.2):
+        import glob
+        import threading
+        self.files, self.rows, self.stop_flag, self.period = None, [], False, period
+        try:
+            p = torch.cuda.get_device_properties(device_index)
+            want = "%04x:%02x:%02x." % (p.pci_domain_id, p.pci_bus_id, p.pci_device_id)
+            for dev in glob.glob("/sys/class/drm/card*/device"):
+                if want in os.path.realpath(dev):
+                    hw = glob.glob(os.path.join(dev, "hwmon", "hwmon*"))
+                    if hw and os.path.exists(os.path.join(hw[0], "power1_input")):
+                        self.files = {k: os.path.join(hw[0], k) for k in ("freq1_input", "power1_input", "power1_cap")}
+                        break
+        except Exception:
+            self.files = None
+        self.thread = threading.Thread(target=self._run, daemon=True) if self.files else None
+
+    @staticmethod
+    def _read(path):
+        try:
+            with open(path) as f:
+                return float(f.read().strip())
+        except Exception:
+            return None
+
+    def _run(self):
+        while not self.stop_flag:
+            self.rows.append((self._read(self.files["freq1_input"]), self._read(self.files["power1_input"])))
+            time.sleep(self.period)
+
+    def start(self):
+        if self.thread:
+            self.thread.start()
+
+    def stop(self):
+        if not self.thread:
+            return None
+        self.stop_flag = True
+        self.thread.join()
+        ck = [r[0] / 1e6 for r in self.rows if r[0]]
+        pw = [r[1] / 1e6 for r in self.rows if r[1]]
+        cap = self._read(self.files["power1_cap"])
+        if not ck or not pw:
+            return None
+        return {"sclk_mhz_mean": sum(ck) / len(ck), "sclk_mhz_min": min(ck), "sclk_mhz_max": max(ck),
+                "socket_power_w_mean": sum(pw) / len(pw), "socket_power_w_max": max(pw),
+                "power_cap_w": cap / 1e6 if cap else None, "samples": len(ck),
+                "source": "amdgpu hwmon (freq1_input, power1_input) sampled every %.1f s over the timed region" % self.period}
+
+
 def rms_check(W, kind, eng, threads):
     """Whole-waveform RMS of the HIP path against the float32 CPU restatement on a FULL short clip
     (0.5 s = 48 frames: every frame, both clip edges, the complete overlap-add)."""
@@ -146,6 +204,9 @@ def main():
 
     W = weights.synthetic_weights(a.kind, 7)
     eng = engine.Engine(a.kind, W, device=local, frames_per_chunk=a.frames_per_chunk or None, precision=a.precision)
+    for kv in a.option:
+        k, v = kv.split("=", 1)
+        eng.set_option(k, int(v))
     mixes, ca, cb, distinct = make_batch(a.kind, rank, a.clips_per_gpu, a.seconds, a.distinct)
     mix_t, mix_off = eng._dev(mixes)
     ca_t, ca_off = eng._dev(ca)
@@ -168,6 +229,9 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
+    sampler = DeviceSampler(local) if rank == 0 else None
+    if sampler:
+        sampler.start()
     t0 = time.perf_counter()
     for _ in range(a.steps):
         res = step()
@@ -175,6 +239,7 @@ def main():
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
+    device_state = sampler.stop() if sampler else None
     status = eng.take_status()                  # sticky: covers every step above
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -230,11 +295,12 @@ def main():
             "config": {"workload": "%d x %.0f s 16 kHz synthetic mixture(s) per GPU, %s model, STFT+embed+mask+iSTFT end-to-end%s"
                                    % (a.clips_per_gpu, a.seconds, a.kind, " + RCCL all-gather" if world > 1 else ""),
                        "clips_per_gpu": a.clips_per_gpu, "distinct_clips_per_gpu": distinct, "frames_per_gpu": frames,
-                       "weights": "synthetic seed 7", "parallelism": "clip-sharded x%d" % world
+                       "weights": "synthetic seed 7", "options": a.option or None, "parallelism": "clip-sharded x%d" % world
                        + (" (ALL RANKS ON ONE DEVICE, gloo: functional check only)" if a.share_device0 else "")},
             "frames_per_s": world * frames * a.steps / dt,
             "x_realtime_per_gpu": audio_s * a.steps / dt,
             "status_flags": status,
+            "device_state": device_state,
             "roofline": {"bound": "mfma", "kernel": "conv_igemm_* (all implicit-GEMM conv launches of a step)",
                          "achieved": tflops, "peak": peak, "unit": "TFLOP/s", "frac": tflops / peak,
                          "traffic": traffic, "traffic_source": traffic_src,
@@ -243,6 +309,12 @@ def main():
                          "algorithmic_gflop_per_launch": conv_fl / conv_calls / 1e9 if conv_calls else None,
                          "executed_tflops": tflops * (3 if a.precision == "f16x3" else 1),
                          "executed_frac": tflops * (3 if a.precision == "f16x3" else 1) / peak,
+                         # what back-to-back f16 MFMAs on random register operands sustain at the socket power cap
+                         # (tools/ubench/mfma_power.hip, profiles/r02/mfma_power_ceiling.txt); the datasheet peak is
+                         # reached with all-zero operands only
+                         "peak_at_power_cap": F16_MFMA_AT_POWER_CAP_TFLOPS if a.precision == "f16x3" else None,
+                         "executed_frac_of_peak_at_power_cap": tflops * 3 / F16_MFMA_AT_POWER_CAP_TFLOPS
+                         if a.precision == "f16x3" else None,
                          "source": "hipEvents around every launch in one extra pass after the timed region (%.1f ms wall)"
                                    % (kpass_ms or 0.0),
                          # the same algorithmic FLOPs over the UNPROFILED timed step (all kernels, launch gaps): lower bound

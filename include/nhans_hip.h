@@ -94,7 +94,11 @@ void nhans_destroy(nhans_ctx* ctx);
  *           reads between their MFMAs; 0: read block then MFMA block -- identical bits, kept for A/B),
  *          "persistent_tiles" (0, default; 1: launches with >= 2 tiles per CU run the halo kernels as persistent
  *           workgroups whose DMA pipeline runs on across tile boundaries -- identical bits, measured 2-3 %
- *           slower, kept so that the measurement can be repeated).
+ *           slower, kept so that the measurement can be repeated),
+ *          "quad_workgroups" (0, default; 1: the stride-1 convs with N % 128 == 0 run on four-wave workgroups, two
+ *           resident per CU, every wave multiplying and issuing DMA (conv_igemm_quad.hip) -- identical bits, 10 %
+ *           fewer clock ticks per tile, and the same wall time because the chip then clocks lower at its socket
+ *           power cap; kept as the measurement of that cap).
  * (A `make DEV=1` build adds "debug_cycles_ptr" and the NHANS_ABLATE / NHANS_HALO2D environment
  * switches used by tools/; the default build has no developer hooks and reads no environment.)
  * Besides the workspace a context holds 64 MB of split-K scratch for the few launches that are

@@ -348,6 +348,9 @@ double launch_conv_igemm(const ConvArgs& a0, hipStream_t s, const char** kernel)
             // the 64-channel stride-1 convs: 512-pixel tiles
             if (launch_conv_igemm_halo_persist(a, s)) name = "conv_igemm_halo_persist<64,512>";
             else { launch_conv_igemm_halo(a, s); name = "conv_igemm_halo<64,512>"; }
+        } else if (halo_ok && wide && a.quad && conv_igemm_quad_eligible(a)) {
+            launch_conv_igemm_quad(a, s);
+            name = "conv_igemm_quad<128>";
         } else if (halo_ok && launch_conv_igemm_halo2d(a, s)) {
             name = "conv_igemm_halo2d<64>";          // (variant 3) 2-D 256-pixel tiles for the same layers
         } else if (halo_ok && (a.halo64_tile512 = 0, conv_igemm_halo_eligible(a))) {

@@ -127,6 +127,7 @@ struct nhans_ctx {
     int epi8 = 1;               // ConvArgs::epi8
     int ilv = 1;                // ConvArgs::ilv
     int persist = 0;            // ConvArgs::persist (measured slower: conv_igemm_halop.hip)
+    int quad = 0;               // ConvArgs::quad
     long long* dbg = nullptr;   // NHANS_DEV builds: per-workgroup cycle stamps of the last conv launch
     int* status_dev = nullptr;  // sticky NHANS_STATUS_* bits set by kernels (nhans_take_status)
     // ordering of consecutive calls that share the workspace (see include/nhans_hip.h)
@@ -231,6 +232,7 @@ void fill_epilogue_defaults(nhans_ctx* c, ConvArgs& a) {
     a.epi8 = c->epi8;
     a.ilv = c->ilv;
     a.persist = c->persist;
+    a.quad = c->quad;
     a.kscratch = c->kscratch; a.kscratch_bytes = c->kscratch_bytes; a.kcounter = c->kcounter; a.kcounter_n = c->kcounter_n; a.kgroup = 0;
 }
 
@@ -702,6 +704,7 @@ int nhans_set_option(nhans_ctx* c, const char* key, int64_t value) {
     else if (k == "epilogue_wide") c->epi8 = value != 0;
     else if (k == "consumer_interleave") c->ilv = value != 0;
     else if (k == "persistent_tiles") c->persist = value != 0;
+    else if (k == "quad_workgroups") c->quad = value != 0;
     else if (k == "conv_variant") {
         if (value < -1 || value > 3) return fail(NHANS_EINVAL, "conv_variant must be -1 (auto), 0, 1, 2 or 3");
         c->conv_variant = (int)value;

@@ -111,6 +111,7 @@ struct ConvArgs {
     int persist;           // halo kernels: persistent workgroups walking several tiles with the DMA pipeline kept
                            // running across tile boundaries (conv_igemm_halop.hip) when the launch has >= 2 tiles
                            // per CU (default 0: measured 2-3 % slower than one tile per workgroup; same bits)
+    int quad;              // N % 128 == 0, f16x3, stride-1 convs: four-wave workgroups, two per CU (conv_igemm_quad.hip)
     int halo64_tile512;    // halo kernel, 64-channel convs: 512-pixel tiles (variant 2) instead of the 2-D
                            // 256-pixel tiles of conv_igemm_halo2d.hip / 256-pixel runs (variant 3)
     long long* dbg;        // NHANS_DEV builds only: 4 s_memtime stamps per workgroup [start, loop, epilogue, end]
@@ -134,6 +135,8 @@ double launch_conv_igemm(const ConvArgs& a, hipStream_t s, const char** kernel =
 void launch_conv_igemm_dma(const ConvArgs& a, hipStream_t s);   // conv_igemm_dma.hip
 bool conv_igemm_halo_eligible(const ConvArgs& a);               // conv_igemm_halo.hip
 void launch_conv_igemm_halo(const ConvArgs& a, hipStream_t s);
+bool conv_igemm_quad_eligible(const ConvArgs& a);                         // conv_igemm_quad.hip
+void launch_conv_igemm_quad(const ConvArgs& a, hipStream_t s);
 bool launch_conv_igemm_halo_persist(const ConvArgs& a, hipStream_t s);   // conv_igemm_halop.hip; false = not applicable, nothing launched
 bool launch_conv_igemm_halo2d(const ConvArgs& a, hipStream_t s);  // conv_igemm_halo2d.hip; false = not eligible, nothing launched
 

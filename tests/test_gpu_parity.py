@@ -178,7 +178,8 @@ def test_mask_net_is_bitwise_reproducible(eng_d):
 
 
 @pytest.mark.parametrize("option, values", [("persistent_tiles", (1, 0)), ("consumer_interleave", (0, 1)),
-                                            ("epilogue_wide", (0, 1)), ("conv_variant", (3, -1))])
+                                            ("epilogue_wide", (0, 1)), ("conv_variant", (3, -1)),
+                                            ("quad_workgroups", (1, 0))])
 def test_speed_knobs_do_not_change_a_bit(_eng_d, option, values):
     """The A/B options of the C ABI select other instruction orders / tile walks of the same arithmetic:
     a 10 s clip (thousands of tiles per layer, so that the persistent kernels really run) must give
@@ -199,6 +200,24 @@ def test_speed_knobs_do_not_change_a_bit(_eng_d, option, values):
             assert torch.equal(got, ref), option
     finally:
         _eng_d.set_option(option, values[1])
+
+
+def test_quad_workgroups_whole_path_bitwise(_eng_d):
+    """Option quad_workgroups (conv_igemm_quad.hip: four-wave workgroups, two per CU, for the N >= 128 stride-1
+    convs of the tower and the stack) must not change a bit of anything: ragged 3-clip batch incl. a one-frame clip."""
+    _eng_d.set_precision("f16x3")
+    mixes = [apply.trim_to_frames(apply.normalise(synth.mixture(40 + i, d))) for i, d in enumerate((0.025, 1.3, 0.6))]
+    ca = [apply.normalise(synth.noise_context(40 + i)) for i in range(3)]
+    cb = [apply.normalise(synth.speaker_context(40 + i)) for i in range(3)]
+    ref = _eng_d.enhance(mixes, ca, cb, want_mixed=False, taps=True)
+    try:
+        _eng_d.set_option("quad_workgroups", 1)
+        got = _eng_d.enhance(mixes, ca, cb, want_mixed=False, taps=True)
+    finally:
+        _eng_d.set_option("quad_workgroups", 0)
+    for k in ("emb", "logits"):
+        assert np.array_equal(got[k], ref[k]), k
+    assert all(np.array_equal(x, y) for x, y in zip(got["denoised_wav"], ref["denoised_wav"]))
 
 
 def test_separator_model(eng_s):
