@@ -380,3 +380,26 @@ def test_separator_mixing_and_trim_quirk():
     sig["c"] = sig["c"][:400 + 160 * 50]
     with pytest.raises(Exception):
         mixing.combine_signals_separator(lambda k: sig[k], "c", "n")
+
+
+def test_bench_device_sampler_degrades_to_none_and_reads_hwmon(tmp_path, monkeypatch):
+    """bench.py's clock/power sampler: no GPU / no hwmon files -> device_state null (never an exception); with
+    hwmon-shaped files it averages freq1_input (Hz) and power1_input (uW)."""
+    import sys
+    import time
+    sys.path.insert(0, ROOT)
+    import bench
+    s = bench.DeviceSampler(0)
+    s.start()
+    assert s.stop() is None
+    for name, val in (("freq1_input", "1950000000"), ("power1_input", "1336000000"), ("power1_cap", "1400000000")):
+        (tmp_path / name).write_text(val + "\n")
+    import threading
+    s = bench.DeviceSampler(0, period=0.01)
+    s.files = {k: str(tmp_path / k) for k in ("freq1_input", "power1_input", "power1_cap")}
+    s.thread = threading.Thread(target=s._run, daemon=True)
+    s.start()
+    time.sleep(0.1)
+    st = s.stop()
+    assert st["samples"] >= 2 and abs(st["sclk_mhz_mean"] - 1950.0) < 1e-6
+    assert abs(st["socket_power_w_mean"] - 1336.0) < 1e-6 and st["power_cap_w"] == 1400.0
