@@ -56,6 +56,9 @@ def parse():
     p.add_argument("--no-kernel-pass", action="store_true", help="skip the extra profiled pass (rocprofv3 runs)")
     p.add_argument("--cpu-frames", type=int, default=32, help="frames of the CPU baseline sample")
     p.add_argument("--cpu-threads", type=int, default=0, help="0 = min(host cores, 64)")
+    p.add_argument("--force-dist", action="store_true",
+                   help="initialise the process group and run the all-gather and barriers even at world size 1 "
+                        "(RCCL smoke on a one-GPU box; launch under torch.distributed.run --nproc-per-node 1)")
     p.add_argument("--share-device0", action="store_true",
                    help="functional check of the N > 1 code path on a one-GPU box: every rank uses device 0 and the "
                         "all-gather runs over gloo (RCCL refuses two ranks on one device); not a measurement")
@@ -192,7 +195,8 @@ def main():
     dist = None
     if a.share_device0:
         local = 0
-    if world > 1:
+    use_dist = world > 1 or a.force_dist
+    if use_dist:
         import torch.distributed as dist
         torch.cuda.set_device(local)
         if a.share_device0:
@@ -214,19 +218,19 @@ def main():
     frames = sum(spec.frames_for_samples(len(m))[1] for m in mixes)
     audio_s = sum(len(m) for m in mixes) / float(spec.FS)
     gathered = None
-    if world > 1:
+    if use_dist:
         gathered = torch.empty(world * mix_off[-1], dtype=torch.float32, device=dev)
 
     def step():
         res = eng.enhance_device(mix_t, mix_off, ca_t, ca_off, cb_t, cb_off)
-        if world > 1:       # the path's one exchange step: reassemble the batch
+        if use_dist:        # the path's one exchange step: reassemble the batch
             dist.all_gather_into_tensor(gathered, res["denoised_wav"])
         return res
 
     for _ in range(a.warmup):
         res = step()
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     sampler = DeviceSampler(local) if rank == 0 else None
@@ -236,12 +240,12 @@ def main():
     for _ in range(a.steps):
         res = step()
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     dt = time.perf_counter() - t0
     device_state = sampler.stop() if sampler else None
     status = eng.take_status()                  # sticky: covers every step above
-    if world > 1:
+    if use_dist:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -293,7 +297,7 @@ def main():
             "dtype": "f32" if a.precision == "f32" else "f16x3 (split hi+lo f16 operands, f32 accumulate)",
             "data": "synthetic",
             "config": {"workload": "%d x %.0f s 16 kHz synthetic mixture(s) per GPU, %s model, STFT+embed+mask+iSTFT end-to-end%s"
-                                   % (a.clips_per_gpu, a.seconds, a.kind, " + RCCL all-gather" if world > 1 else ""),
+                                   % (a.clips_per_gpu, a.seconds, a.kind, " + RCCL all-gather" if use_dist else ""),
                        "clips_per_gpu": a.clips_per_gpu, "distinct_clips_per_gpu": distinct, "frames_per_gpu": frames,
                        "weights": "synthetic seed 7", "options": a.option or None, "parallelism": "clip-sharded x%d" % world
                        + (" (ALL RANKS ON ONE DEVICE, gloo: functional check only)" if a.share_device0 else "")},
@@ -335,7 +339,7 @@ def main():
             line["rms_vs_cpu_f32"] = chk["rms"]
             line["rms_check"] = chk
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
     eng.close()

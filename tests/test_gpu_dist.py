@@ -78,11 +78,11 @@ def _rank_main(rank, world, port, backend, q):
         q.put((rank, False, traceback.format_exc() + repr(e)))
 
 
-def _run_two_ranks(backend):
+def _run_two_ranks(backend, world=2):
     ctx = mp.get_context("forkserver")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_rank_main, args=(r, 2, port, backend, q)) for r in range(2)]
+    procs = [ctx.Process(target=_rank_main, args=(r, world, port, backend, q)) for r in range(world)]
     for p in procs:
         p.start()
     try:
@@ -115,6 +115,14 @@ def _check(res, ref):
 
 def test_two_ranks_one_gpu_gloo_equals_single_process(lib_built):
     res = _run_two_ranks("gloo")              # workers first: this process has not touched the GPU yet
+    _check(res, _single_process_reference())
+
+
+def test_one_rank_rccl_collectives_equal_single_process(lib_built):
+    """The RCCL leg of dist.enhance_sharded on the one GPU there is: process group over "nccl" with one rank, the
+    lengths gather and the padded all-gather on DEVICE tensors (library load, communicator init, collectives,
+    teardown) -- what the two-rank RCCL test below needs a second GPU for."""
+    res = _run_two_ranks("nccl", world=1)
     _check(res, _single_process_reference())
 
 

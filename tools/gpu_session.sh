@@ -38,4 +38,7 @@ if has dist1; then
   timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 \
       bench.py --gpus 2 --steps 2 --warmup 1 --clips-per-gpu 8 --share-device0 --no-kernel-pass > $OUT/bench_2ranks_shared.json 2> $OUT/bench_2ranks_shared.err; echo "dist1 rc=$?"
   tail -c 1500 $OUT/bench_2ranks_shared.json
+  # and its RCCL leg with the one rank a one-GPU box allows (communicator init, all-gather, barriers, all-reduce)
+  timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29533 \
+      bench.py --gpus 1 --steps 2 --warmup 1 --clips-per-gpu 16 --force-dist --no-cpu-baseline > $OUT/bench_rccl_1rank.json 2> $OUT/bench_rccl_1rank.err; echo "rccl1 rc=$?"
 fi
