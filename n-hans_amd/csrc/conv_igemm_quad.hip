@@ -231,7 +231,7 @@ __global__ void __launch_bounds__(QW * 64, 2) conv_igemm_quad(const ConvArgs a) 
     // "DMA slot 0" (what the loop does after barrier(it-1) for it = 0): weights of tap 1, image of super-chunk 1
     NQ_ISSUE_B(1)
     NQ_ISSUE_A(1)
-    bool img_in_flight = !(segC == 0 && KW0 == 1);     // the image just issued may stay in flight across barrier(0)
+    bool img_in_flight = true;                          // super-chunk 1 opens KW0 >= 3 taps from now: may cross barrier(0)
     NQ_READ_HALF(0, 0)
     int stC = 0;                                        // ring stage of tap `it`
     for (int it = 0; it < total; ++it) {
