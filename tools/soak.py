@@ -17,8 +17,10 @@ from nhans_amd.apply import normalise, trim_to_frames  # noqa: E402
 def main():
     runs = int(sys.argv[1]) if len(sys.argv) > 1 else 100
     clips = int(sys.argv[2]) if len(sys.argv) > 2 else 2
-    for prec in ("f16x3", "f32"):
+    for prec, opts in (("f16x3", {}), ("f16x3", {"quad_workgroups": 1}), ("f32", {})):
         eng = engine.Engine("denoiser", precision=prec)
+        for k, v in opts.items():
+            eng.set_option(k, v)
         mixes = [trim_to_frames(normalise(synth.mixture(i, 10.0 if i % 2 == 0 else 3.7))) for i in range(clips)]
         ca = [normalise(synth.silent()) for _ in range(clips)]
         cb = [normalise(synth.noise_context(i)) for i in range(clips)]
@@ -33,7 +35,7 @@ def main():
                     if not np.array_equal(a, b):
                         print("MISMATCH at run", r, prec, float(np.abs(a - b).max()))
                         sys.exit(1)
-        print(prec, "ok:", runs, "runs x", clips, "clips bit-identical")
+        print(prec, opts or "", "ok:", runs, "runs x", clips, "clips bit-identical")
         eng.close()
 
 
