@@ -289,7 +289,10 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[T
     // 2. per-pixel (clip, h, w, 1-channel residual index)
     if (tid < BMROWS) {
         const int mz = tile(tid, a);
-        const int m = mz < 0 ? tile(0, a) : mz;          // (slots past the end look like the tile's first pixel; never stored)
+        // slots past the end are never stored; they must look like the LAST valid pixel of a linear tile, because
+        // "first row's clip == last row's clip" below decides whether one bias vector serves the whole tile (a
+        // partial last tile that looked like its first pixel there gave the next clip's first frame the wrong bias)
+        const int m = mz < 0 ? (tile.tw > 0 ? tile(0, a) : a.M - 1) : mz;
         const uint32_t b = fd_div((uint32_t)m, a.fdHoWo);
         const uint32_t rem = (uint32_t)m - b * a.fdHoWo.d;
         const uint32_t ho = fd_div(rem, a.fdWo);
@@ -317,7 +320,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[T
         const int c8 = tid % C8, prow8 = tid / C8;
         const int n8 = n_tile0 + c8 * 8;
         // one clip for the whole tile (pixels are ordered by clip, so first == last decides; rows past
-        // the end of the tensor carry the first row's clip): its bias vector is loaded once per thread
+        // the end of the tensor carry the last valid row's clip): its bias vector is loaded once per thread
         const bool one_clip = rowinfo[0].x == rowinfo[BMROWS - 1].x;
         const int mode8 = (a.id_mode == 0 ? 0 : a.id_mode == 1 ? 1 : 2) * 2 + (one_clip ? 1 : 0);
         switch (mode8) {

@@ -202,6 +202,34 @@ def test_speed_knobs_do_not_change_a_bit(_eng_d, option, values):
         _eng_d.set_option(option, values[1])
 
 
+@pytest.mark.parametrize("quad", [0, 1])
+def test_clip_boundary_inside_the_partial_last_tile(_eng_d, quad):
+    """Regression (found by tools/fuzz_batches.py): a batch whose LAST tile is partial and holds the end of one clip
+    and the one-frame clip after it.  The epilogue decides "one clip per tile -> load the conditioning bias once"
+    from the first and last row of the tile; rows past the end used to look like the first row, so the last clip's
+    frame got its neighbour's bias (logits off by up to 7e-2).  Every clip must equal the same clip run alone."""
+    _eng_d.set_precision("f16x3")
+    secs = (0.1, 0.025, 0.33, 0.025)                        # 8 + 1 + 31 + 1 frames; different conditioning per clip
+    mixes = [apply.trim_to_frames(apply.normalise(synth.mixture(70 + i, d))) for i, d in enumerate(secs)]
+    ca = [apply.normalise(synth.noise_context(80 + i)) for i in range(len(secs))]
+    cb = [apply.normalise(synth.speaker_context(90 + i)) for i in range(len(secs))]
+    try:
+        _eng_d.set_option("quad_workgroups", quad)
+        alone = [_eng_d.enhance([mixes[i]], [ca[i]], [cb[i]], want_mixed=False, taps=True)["logits"] for i in range(len(secs))]
+        for ids in ([0, 1], [2, 3], [0, 1, 2, 3], [3, 2, 1, 0]):
+            for fpc in (3776, 9, 4):
+                _eng_d.set_option("frames_per_chunk", fpc)
+                got = _eng_d.enhance([mixes[i] for i in ids], [ca[i] for i in ids], [cb[i] for i in ids],
+                                     want_mixed=False, taps=True)["logits"]
+                f0 = 0
+                for i in ids:
+                    assert np.array_equal(got[f0:f0 + len(alone[i])], alone[i]), (ids, fpc, i)
+                    f0 += len(alone[i])
+    finally:
+        _eng_d.set_option("frames_per_chunk", 3776)
+        _eng_d.set_option("quad_workgroups", 0)
+
+
 def test_quad_workgroups_whole_path_bitwise(_eng_d):
     """Option quad_workgroups (conv_igemm_quad.hip: four-wave workgroups, two per CU, for the N >= 128 stride-1
     convs of the tower and the stack) must not change a bit of anything: ragged 3-clip batch incl. a one-frame clip."""

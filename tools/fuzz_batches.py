@@ -1,0 +1,68 @@
+"""Randomised batch / chunk invariance screen on the GPU: random ragged batches (1..6 clips of 1..250 frames), random
+frames_per_chunk, quad_workgroups on or off, both models -- every clip's logits and waveform must equal, bit for
+bit, the same clip run alone with the default settings, and be finite.  Exercises the tile-boundary handling of
+every conv kernel at many M that no fixed test hits.
+    python tools/fuzz_batches.py [iterations] [seed]"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import nhans_amd  # noqa: E402,F401
+from nhans_amd import engine, synth  # noqa: E402
+from nhans_amd.apply import normalise, trim_to_frames  # noqa: E402
+
+
+def main():
+    iters = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+    rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+    bad = 0
+    for kind in ("denoiser", "separator"):
+        eng = engine.Engine(kind, precision="f16x3")
+        alone = {}
+        pool = []
+        for i in range(12):
+            secs = float(rng.choice([0.025, 0.035, 0.1, 0.33, 0.8, 1.7, 2.5]))
+            mix = trim_to_frames(normalise(synth.mixture(500 + i, secs)))
+            ca = normalise(synth.silent()) if kind == "denoiser" else normalise(synth.speaker_context(500 + i, low=True))
+            cb = normalise(synth.noise_context(500 + i)) if kind == "denoiser" else normalise(synth.speaker_context(500 + i, low=False))
+            pool.append((mix, ca, cb))
+            r = eng.enhance([mix], [ca], [cb], want_mixed=False, taps=True)
+            alone[i] = (r["logits"].copy(), r["denoised_wav"][0].copy(), r["emb"].copy(), r["logmag"].copy())
+        for it in range(iters):
+            n = int(rng.integers(1, 7))
+            ids = [int(x) for x in rng.integers(0, len(pool), n)]
+            fpc = int(rng.choice([1, 7, 33, 100, 257, 1024, 3776]))
+            quad = int(rng.integers(0, 2))
+            eng.set_option("frames_per_chunk", fpc)
+            eng.set_option("quad_workgroups", quad)
+            r = eng.enhance([pool[i][0] for i in ids], [pool[i][1] for i in ids], [pool[i][2] for i in ids],
+                            want_mixed=False, taps=True)
+            f0 = 0
+            for k, i in enumerate(ids):
+                lg, wav, emb, lm = alone[i]
+                got_lg = r["logits"][f0:f0 + len(lg)]
+                got_lm = r["logmag"][f0:f0 + len(lg)]
+                got_emb = r["emb"][[k, n + k]]
+                f0 += len(lg)
+                ok = np.array_equal(got_lg, lg) and np.array_equal(r["denoised_wav"][k], wav) and np.isfinite(wav).all()
+                if not ok:
+                    bad += 1
+                    fr = np.abs(got_lg - lg).max(axis=1)
+                    print("MISMATCH", kind, "iter", it, "clip", i, "pos", k, "of", ids, "fpc", fpc, "quad", quad,
+                          "logits %.3g" % float(fr.max()), "frames differing", int((fr > 0).sum()), "of", len(fr),
+                          "first", int(np.argmax(fr > 0)), "| emb %.3g" % float(np.abs(got_emb - emb).max()),
+                          "| logmag %.3g" % float(np.abs(got_lm - lm).max()), "| frames before", f0 - len(lg))
+        eng.set_option("frames_per_chunk", 3776)
+        eng.set_option("quad_workgroups", 0)
+        eng.close()
+        print(kind, "done:", iters, "random batches")
+    print("fuzz: %d mismatches" % bad)
+    sys.exit(1 if bad else 0)
+
+
+if __name__ == "__main__":
+    main()
