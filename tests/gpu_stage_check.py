@@ -1,6 +1,7 @@
 """Stage-by-stage comparison of the HIP path against the float64 oracle on one short clip
-(development aid; the pytest -m gpu suite is the real gate).  Usage on a GPU box:
-    python tools/gpu_stage_check.py [seconds]"""
+(development aid, kept under tests/ because only tests may use the oracle; the pytest -m gpu suite is the real gate).
+Usage on a GPU box:
+    python tests/gpu_stage_check.py [seconds]"""
 import os
 import sys
 import time
