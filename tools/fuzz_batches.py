@@ -1,7 +1,9 @@
-"""Randomised batch / chunk invariance screen on the GPU: random ragged batches (1..6 clips of 1..250 frames), random
-frames_per_chunk, quad_workgroups on or off, both models -- every clip's logits and waveform must equal, bit for
-bit, the same clip run alone with the default settings, and be finite.  Exercises the tile-boundary handling of
-every conv kernel at many M that no fixed test hits.
+"""Randomised batch / chunk / knob invariance screen on the GPU: random ragged batches (1..8 clips of 1..998 frames),
+random frames_per_chunk, arithmetic mode and conv_variant, and a random setting of every knob that is bit-identical
+by contract (quad_workgroups, persistent_tiles, epilogue_wide, consumer_interleave), both models -- every clip's
+logits and waveform must equal, bit for bit, the same clip run alone with the default knobs (same arithmetic mode
+and conv_variant), and be finite.  Exercises the tile-boundary handling of every conv kernel at many M that no
+fixed test hits.
     python tools/fuzz_batches.py [iterations] [seed]"""
 import os
 import sys
@@ -20,30 +22,49 @@ def main():
     iters = int(sys.argv[1]) if len(sys.argv) > 1 else 40
     rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
     bad = 0
+    knobs = ("quad_workgroups", "persistent_tiles", "epilogue_wide", "consumer_interleave")     # bit-identical by contract
+    defaults = {"quad_workgroups": 0, "persistent_tiles": 0, "epilogue_wide": 1, "consumer_interleave": 1}
     for kind in ("denoiser", "separator"):
         eng = engine.Engine(kind, precision="f16x3")
-        alone = {}
         pool = []
-        for i in range(12):
-            secs = float(rng.choice([0.025, 0.035, 0.1, 0.33, 0.8, 1.7, 2.5]))
+        for i in range(14):
+            secs = float(rng.choice([0.025, 0.035, 0.1, 0.33, 0.8, 1.7, 2.5, 5.0, 10.0], p=[.15, .1, .15, .15, .15, .1, .1, .05, .05]))
             mix = trim_to_frames(normalise(synth.mixture(500 + i, secs)))
             ca = normalise(synth.silent()) if kind == "denoiser" else normalise(synth.speaker_context(500 + i, low=True))
             cb = normalise(synth.noise_context(500 + i)) if kind == "denoiser" else normalise(synth.speaker_context(500 + i, low=False))
             pool.append((mix, ca, cb))
-            r = eng.enhance([mix], [ca], [cb], want_mixed=False, taps=True)
-            alone[i] = (r["logits"].copy(), r["denoised_wav"][0].copy(), r["emb"].copy(), r["logmag"].copy())
+        alone = {}                                      # (precision, conv_variant, clip) -> results with default knobs
+
+        def reference(prec, variant, i):
+            key = (prec, variant, i)
+            if key not in alone:
+                eng.set_precision(prec)
+                eng.set_option("conv_variant", variant)
+                eng.set_option("frames_per_chunk", 3776)
+                for k, v in defaults.items():
+                    eng.set_option(k, v)
+                r = eng.enhance([pool[i][0]], [pool[i][1]], [pool[i][2]], want_mixed=False, taps=True)
+                alone[key] = (r["logits"].copy(), r["denoised_wav"][0].copy(), r["emb"].copy(), r["logmag"].copy())
+            return alone[key]
+
         for it in range(iters):
-            n = int(rng.integers(1, 7))
+            n = int(rng.integers(1, 9))
             ids = [int(x) for x in rng.integers(0, len(pool), n)]
+            prec = "f16x3" if rng.random() < 0.8 else "f32"
+            variant = int(rng.choice([-1, -1, 0, 1, 2, 3]))
+            refs = [reference(prec, variant, i) for i in ids]
             fpc = int(rng.choice([1, 7, 33, 100, 257, 1024, 3776]))
-            quad = int(rng.integers(0, 2))
+            cfg = {k: int(rng.integers(0, 2)) for k in knobs}
+            eng.set_precision(prec)
+            eng.set_option("conv_variant", variant)
             eng.set_option("frames_per_chunk", fpc)
-            eng.set_option("quad_workgroups", quad)
+            for k, v in cfg.items():
+                eng.set_option(k, v)
             r = eng.enhance([pool[i][0] for i in ids], [pool[i][1] for i in ids], [pool[i][2] for i in ids],
                             want_mixed=False, taps=True)
             f0 = 0
             for k, i in enumerate(ids):
-                lg, wav, emb, lm = alone[i]
+                lg, wav, emb, lm = refs[k]
                 got_lg = r["logits"][f0:f0 + len(lg)]
                 got_lm = r["logmag"][f0:f0 + len(lg)]
                 got_emb = r["emb"][[k, n + k]]
@@ -52,12 +73,10 @@ def main():
                 if not ok:
                     bad += 1
                     fr = np.abs(got_lg - lg).max(axis=1)
-                    print("MISMATCH", kind, "iter", it, "clip", i, "pos", k, "of", ids, "fpc", fpc, "quad", quad,
+                    print("MISMATCH", kind, "iter", it, "clip", i, "pos", k, "of", ids, prec, "variant", variant, "fpc", fpc, cfg,
                           "logits %.3g" % float(fr.max()), "frames differing", int((fr > 0).sum()), "of", len(fr),
                           "first", int(np.argmax(fr > 0)), "| emb %.3g" % float(np.abs(got_emb - emb).max()),
                           "| logmag %.3g" % float(np.abs(got_lm - lm).max()), "| frames before", f0 - len(lg))
-        eng.set_option("frames_per_chunk", 3776)
-        eng.set_option("quad_workgroups", 0)
         eng.close()
         print(kind, "done:", iters, "random batches")
     print("fuzz: %d mismatches" % bad)
