@@ -1,0 +1,117 @@
+"""Edges of the C ABI itself (include/nhans_hip.h), called the way a foreign binding would: streams, argument
+errors, a clip too short to have a frame in the middle of a batch, two contexts alive at once."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+import nhans_amd  # noqa: F401
+from nhans_amd import apply, engine, hip, spec, synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng(lib_built, weights_denoiser):
+    e = engine.Engine("denoiser", weights_denoiser, precision="f16x3")
+    yield e
+    e.close()
+
+
+def _batch(seed, secs):
+    mixes = [apply.trim_to_frames(apply.normalise(synth.mixture(seed + i, s))) for i, s in enumerate(secs)]
+    ca = [apply.normalise(synth.noise_context(seed + i)) for i in range(len(secs))]
+    cb = [apply.normalise(synth.speaker_context(seed + i)) for i in range(len(secs))]
+    return mixes, ca, cb
+
+
+def test_consecutive_calls_on_different_streams_are_ordered(eng):
+    """One context, one workspace: a call on stream B issued right behind a call on stream A (no host sync in
+    between) must wait for it (the library orders them with an event) -- both results equal their solo runs."""
+    b1, b2 = _batch(600, (1.0, 0.3)), _batch(610, (0.5, 0.8, 0.2))
+    solo = [eng.enhance(*b, want_mixed=False, taps=True) for b in (b1, b2)]
+    dev = [[eng._dev(x) for x in b] for b in (b1, b2)]
+    torch.cuda.synchronize()
+    sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+    for _ in range(3):
+        with torch.cuda.stream(sa):
+            r1 = eng.enhance_device(dev[0][0][0], dev[0][0][1], dev[0][1][0], dev[0][1][1], dev[0][2][0], dev[0][2][1], taps=True)
+        with torch.cuda.stream(sb):
+            r2 = eng.enhance_device(dev[1][0][0], dev[1][0][1], dev[1][1][0], dev[1][1][1], dev[1][2][0], dev[1][2][1], taps=True)
+        with torch.cuda.stream(sa):                     # and back, reusing the workspace a third time
+            r3 = eng.enhance_device(dev[0][0][0], dev[0][0][1], dev[0][1][0], dev[0][1][1], dev[0][2][0], dev[0][2][1], taps=True)
+        torch.cuda.synchronize()
+        assert np.array_equal(r1["logits"].cpu().numpy(), solo[0]["logits"])
+        assert np.array_equal(r2["logits"].cpu().numpy(), solo[1]["logits"])
+        assert np.array_equal(r3["logits"].cpu().numpy(), solo[0]["logits"])
+        assert np.array_equal(r2["denoised_wav"].cpu().numpy(), np.concatenate(solo[1]["denoised_wav"]))
+    assert eng.take_status() == 0
+
+
+def test_argument_errors_come_back_as_codes_with_a_message(eng):
+    lib = eng.lib
+    z = ctypes.c_void_p(None)
+    off = hip.i64_array([0, 560])
+    assert lib.nhans_enhance_clips(eng.handle, z, off, 1, z, off, z, off, z, z, z, z, z, z, None) == -1     # NHANS_EINVAL
+    assert b"null" in lib.nhans_last_error()
+    assert lib.nhans_set_option(eng.handle, b"no_such_option", 1) == -1 and b"no_such_option" in lib.nhans_last_error()
+    assert lib.nhans_set_option(eng.handle, b"conv_variant", 7) == -1
+    assert lib.nhans_set_option(eng.handle, b"frames_per_chunk", 0) == -1
+    assert lib.nhans_set_option(None, b"profile", 1) == -1
+    # an untrimmed mixture is refused (the reference trims before the STFT, SN/apply.py:157-161), nothing is launched
+    wav = torch.zeros(600, device="cuda")
+    ctxw = torch.zeros(48000, device="cuda")
+    out = torch.zeros(600, device="cuda")
+    rc = lib.nhans_enhance_clips(eng.handle, hip.ptr(wav), hip.i64_array([0, 600]), 1, hip.ptr(ctxw), hip.i64_array([0, 48000]),
+                                 hip.ptr(ctxw), hip.i64_array([0, 48000]), hip.ptr(out), None, None, None, None, None, None)
+    assert rc == -1 and b"whole frame count" in lib.nhans_last_error()
+    # a conditioning recording with fewer than 200 frames: NHANS_ESHORT
+    short = torch.zeros(16000, device="cuda")
+    wav = torch.zeros(560, device="cuda")
+    rc = lib.nhans_enhance_clips(eng.handle, hip.ptr(wav), hip.i64_array([0, 560]), 1, hip.ptr(short), hip.i64_array([0, 16000]),
+                                 hip.ptr(ctxw), hip.i64_array([0, 48000]), hip.ptr(out), None, None, None, None, None, None)
+    assert rc < 0 and b"frames" in lib.nhans_last_error()
+    assert eng.take_status() == 0
+
+
+def test_clip_without_a_frame_inside_a_batch_leaves_its_neighbours_alone(eng):
+    """Straight at the ABI (the Python engine refuses such a clip): a 300-sample clip between two real ones has no
+    STFT frame; its neighbours must come out exactly as they do without it, its own output stays untouched."""
+    mixes, ca, cb = _batch(620, (0.4, 0.3))
+    solo = eng.enhance(mixes, ca, cb, want_mixed=False, taps=True)
+    stub = np.full(300, 0.25, np.float32)
+    mix3 = [mixes[0], stub, mixes[1]]
+    ctx_a, ctx_b = [ca[0], ca[0], ca[1]], [cb[0], cb[1], cb[1]]
+    mt, mo = eng._dev(mix3)
+    at, ao = eng._dev(ctx_a)
+    bt, bo = eng._dev(ctx_b)
+    out = torch.full((mo[-1],), 7.0, dtype=torch.float32, device="cuda")
+    total = sum(spec.frames_for_samples(len(m))[1] for m in (mixes[0], mixes[1]))
+    logits = torch.empty((total, spec.BINS), dtype=torch.float32, device="cuda")
+    hip.check(eng.lib.nhans_enhance_clips(eng.handle, hip.ptr(mt), hip.i64_array(mo), 3, hip.ptr(at), hip.i64_array(ao),
+                                          hip.ptr(bt), hip.i64_array(bo), hip.ptr(out), None, None, None, hip.ptr(logits), None,
+                                          eng._stream()))
+    torch.cuda.synchronize()
+    out = out.cpu().numpy()
+    assert np.array_equal(out[mo[0]:mo[1]], solo["denoised_wav"][0]) and np.array_equal(out[mo[2]:mo[3]], solo["denoised_wav"][1])
+    assert np.all(out[mo[1]:mo[2]] == 7.0)
+    assert np.array_equal(logits.cpu().numpy(), solo["logits"])
+
+
+def test_two_contexts_of_both_models_interleaved(lib_built, weights_denoiser, weights_separator):
+    """Contexts are independent (one per model here, alive together, calls interleaved): neither disturbs the other."""
+    ed = engine.Engine("denoiser", weights_denoiser, precision="f16x3")
+    es = engine.Engine("separator", weights_separator, precision="f16x3")
+    try:
+        b = _batch(630, (0.6, 0.2))
+        rd0 = ed.enhance(*b, want_mixed=False, taps=True)
+        rs0 = es.enhance(*b, want_mixed=False, taps=True)
+        for _ in range(2):
+            rd = ed.enhance(*b, want_mixed=False, taps=True)
+            rs = es.enhance(*b, want_mixed=False, taps=True)
+            assert np.array_equal(rd["logits"], rd0["logits"]) and np.array_equal(rs["logits"], rs0["logits"])
+        assert not np.array_equal(rd0["logits"], rs0["logits"])
+    finally:
+        ed.close()
+        es.close()
