@@ -119,6 +119,31 @@ def test_batch_of_256_ten_second_clips(eng):
         assert float((rt[i][240:-240] - x[240:-240]).abs().max()) < 2e-4
 
 
+def test_chunk_beyond_the_32bit_offset_limit_of_the_halo_kernels(eng):
+    """frames_per_chunk is a free option: 6,000 frame windows make the 64-channel tensors 2.7e9 elements, past the
+    32-bit element offsets of the halo kernels -- those layers must fall back to the 64-bit-offset LDS-DMA kernel
+    (checked through the profile) and the result must agree with the default chunking to rounding, finite, unsaturated."""
+    eng.set_precision("f16x3")
+    clips = [_clip(900 + i, 10.0) for i in range(6)]                     # 5,988 frames: one chunk of 6,000
+    args = ([c[0] for c in clips], [c[1] for c in clips], [c[2] for c in clips])
+    ref = eng.enhance(*args, want_mixed=False, taps=True)
+    try:
+        eng.set_option("frames_per_chunk", 6000)
+        eng.set_option("profile", 1)
+        eng.profile_reset()
+        got = eng.enhance(*args, want_mixed=False, taps=True)
+        calls = {k: v["calls"] for k, v in eng.profile().items() if k.startswith("conv_igemm")}
+    finally:
+        eng.set_option("profile", 0)
+        eng.set_option("frames_per_chunk", 3776)
+    # the three 64-channel convs of the one stack chunk on the fallback kernel; the halo<64,512> launch left is the tower's
+    assert calls.get("conv_igemm_dma<64>") == 3 and calls.get("conv_igemm_halo<64,512>") == 1, calls
+    assert np.isfinite(got["logits"]).all() and eng.take_status() == 0
+    assert np.abs(got["logits"] - ref["logits"]).max() < LOGIT_TOL
+    for a, b in zip(got["denoised_wav"], ref["denoised_wav"]):
+        assert np.sqrt(np.mean((a - b) ** 2)) < 1e-5
+
+
 @pytest.mark.parametrize("prec", ["f32", "f16x3"])
 def test_separator_ten_second_clip(eng_sep, prec):
     eng_sep.set_precision(prec)
