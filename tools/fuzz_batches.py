@@ -1,5 +1,5 @@
 """Randomised batch / chunk / knob invariance screen on the GPU: random ragged batches (1..8 clips of 1..998 frames),
-random frames_per_chunk, arithmetic mode and conv_variant, and a random setting of every knob that is bit-identical
+random frames_per_chunk and contexts_per_chunk, arithmetic mode and conv_variant, and a random setting of every knob that is bit-identical
 by contract (quad_workgroups, persistent_tiles, epilogue_wide, consumer_interleave), both models -- every clip's
 logits and waveform must equal, bit for bit, the same clip run alone with the default knobs (same arithmetic mode
 and conv_variant), and be finite.  Exercises the tile-boundary handling of every conv kernel at many M that no
@@ -43,6 +43,7 @@ def main():
                 eng.set_option("frames_per_chunk", 3776)
                 for k, v in defaults.items():
                     eng.set_option(k, v)
+                eng.set_option("contexts_per_chunk", 64)
                 r = eng.enhance([pool[i][0]], [pool[i][1]], [pool[i][2]], want_mixed=False, taps=True)
                 alone[key] = (r["logits"].copy(), r["denoised_wav"][0].copy(), r["emb"].copy(), r["logmag"].copy())
             return alone[key]
@@ -55,6 +56,7 @@ def main():
             refs = [reference(prec, variant, i) for i in ids]
             fpc = int(rng.choice([1, 7, 33, 100, 257, 1024, 3776]))
             cfg = {k: int(rng.integers(0, 2)) for k in knobs}
+            cfg["contexts_per_chunk"] = int(rng.choice([1, 3, 5, 64]))      # tower passes with a remainder chunk
             eng.set_precision(prec)
             eng.set_option("conv_variant", variant)
             eng.set_option("frames_per_chunk", fpc)
