@@ -95,6 +95,14 @@ __global__ void __launch_bounds__(768) k(float* out, const float* src, int taps)
     out[blockIdx.x * 512 + tid] = s;
 }
 
+// the DMA'd bytes become MFMA operands: they must look like data too (an all-zero source would make the MFMAs cheap)
+__global__ void fill(float* p, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        unsigned x = (unsigned)(i + 1) * 2654435761u;
+        p[i] = __uint_as_float(0x38003800u ^ (x & 0x03ff03ffu));
+    }
+}
+
 template <int NDMA, int SHARED> void run(const float* src, double secs) {
     const int blocks = 256, taps = 40000;
     float* out; (void)hipMalloc(&out, blocks * 512 * 4);
@@ -118,7 +126,9 @@ template <int NDMA, int SHARED> void run(const float* src, double secs) {
 int main(int argc, char** argv) {
     const double secs = argc > 1 ? atof(argv[1]) : 4.0;
     const size_t n = (size_t)(1 << 20) + (size_t)256 * 4 * (1 << 18);
-    float* src; (void)hipMalloc(&src, n * 4); (void)hipMemset(src, 0, n * 4);
+    float* src; (void)hipMalloc(&src, n * 4);
+    hipLaunchKernelGGL(fill, dim3(4096), dim3(256), 0, 0, src, n);
+    (void)hipDeviceSynchronize();
     run<0, 1>(src, secs); run<3, 1>(src, secs); run<7, 1>(src, secs); run<10, 1>(src, secs); run<14, 1>(src, secs);
     run<3, 0>(src, secs); run<7, 0>(src, secs); run<10, 0>(src, secs);
     return 0;
