@@ -14,6 +14,14 @@
 
 namespace nhans {
 
+#if defined(__HIPCC__)
+// A native 2-vector on the device: re/im live in an aligned register pair from the start, so the packed-f32
+// instructions (v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32) apply without register shuffling.
+typedef float cplx __attribute__((ext_vector_type(2)));
+NH_HD cplx cmake(float x, float y) { return cplx{x, y}; }
+NH_HD cplx cadd(cplx a, cplx b) { return a + b; }
+NH_HD cplx csub(cplx a, cplx b) { return a - b; }
+#else
 struct cplx {
     float x, y;
 };
@@ -21,6 +29,7 @@ struct cplx {
 NH_HD cplx cmake(float x, float y) { cplx r; r.x = x; r.y = y; return r; }
 NH_HD cplx cadd(cplx a, cplx b) { return cmake(a.x + b.x, a.y + b.y); }
 NH_HD cplx csub(cplx a, cplx b) { return cmake(a.x - b.x, a.y - b.y); }
+#endif
 NH_HD cplx cmul(cplx a, cplx b) { return cmake(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
 NH_HD cplx cconj(cplx a) { return cmake(a.x, -a.y); }
 // multiply by -i (forward) or +i (inverse)

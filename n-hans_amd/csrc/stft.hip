@@ -177,7 +177,7 @@ void launch_stft(const float* wav, ClipTable t, const int* block_clip, const int
 // Inverse: two frames per complex transform as well.  With A, B the (Hermitian) spectra of frames a and b,
 // Z = A + iB has the inverse transform z = a + i b: real part = frame a, imaginary part = frame b.  The DC and
 // Nyquist bins enter with their imaginary parts dropped, which is what a real inverse FFT does with them.
-__global__ void __launch_bounds__(256) istft_ola_kernel(
+__global__ void __launch_bounds__(256, 2) istft_ola_kernel(
     const float* __restrict__ logmag, const float* __restrict__ phase, ClipTable tab,
     const int* __restrict__ block_clip, const int* __restrict__ block_h0, int nblocks, const cplx* __restrict__ tw400g,
     const float* __restrict__ wsyng, float* __restrict__ wav_out) {
@@ -311,7 +311,7 @@ void launch_istft(const float* logmag, const float* phase, ClipTable t, const in
     constexpr size_t lds = (400 + 4 * kFpw * kTFrame) * sizeof(cplx) + kWin * sizeof(float);     // 45 KB
     static unsigned long long attr_devices = 0;
     set_max_dynamic_lds(reinterpret_cast<const void*>(&istft_ola_kernel), lds, &attr_devices, "istft_ola");
-    const int grid = nblocks < 256 * 3 ? nblocks : 256 * 3;     // three resident workgroups per CU (LDS), two by registers
+    const int grid = nblocks < 256 * 2 ? nblocks : 256 * 2;     // two resident workgroups per CU (256 registers per lane; LDS would allow three)
     NHANS_LAUNCH("istft_ola", istft_ola_kernel, dim3(grid), dim3(256), lds, s, logmag, phase, t, block_clip,
                  block_h0, nblocks, reinterpret_cast<const cplx*>(tw400), wsyn, wav_out);
 }
