@@ -66,6 +66,15 @@ __device__ __forceinline__ void fast_sincos(float a, float* sn, float* cs) {   /
 }
 
 
+// Global access as (wave-uniform 64-bit base) + (32-bit BYTE offset per lane): the form the scalar-base global
+// instructions take directly; element indexing would make the compiler widen every offset to 64 bits first.
+__device__ __forceinline__ float ldg32(const float* base, unsigned byte_off) {
+    return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + byte_off);
+}
+__device__ __forceinline__ void stg32(float* base, unsigned byte_off, float v) {
+    *reinterpret_cast<float*>(reinterpret_cast<char*>(base) + byte_off) = v;
+}
+
 // A wavefront's transpose / spectrum area is private to it: its lanes exchange data through it with no
 // workgroup barrier, only "my LDS traffic has completed" (lanes of a wave run in lockstep).
 __device__ __forceinline__ void wave_lds_sync() {
@@ -96,11 +105,13 @@ __global__ void __launch_bounds__(256) stft_features_kernel(
     float pre[NPRE];
     auto fetch = [&](int blk) {                     // the run's samples -> registers (loads stay in flight)
         const int c = block_clip[blk];
-        const int64_t base = tab.sample_off[c] + (int64_t)block_f0[blk] * kHop, end = tab.sample_off[c + 1];
+        const int64_t base = tab.sample_off[c] + (int64_t)block_f0[blk] * kHop;
+        const int left = (int)min((int64_t)SPAN, tab.sample_off[c + 1] - base);      // samples of the run inside the clip
+        const float* __restrict__ wb = wav + base;                                   // uniform base + 32-bit lane offset
 #pragma unroll
         for (int u = 0; u < NPRE; ++u) {
             const int i = u * 256 + tid;
-            pre[u] = (i < SPAN && base + i < end) ? wav[base + i] : 0.f;
+            pre[u] = i < left ? ldg32(wb, (unsigned)i * 4u) : 0.f;
         }
     };
     for (int i = tid; i < 400; i += 256) { tw[i] = tw400g[i]; win[i] = windowg[i]; }
@@ -151,14 +162,16 @@ __global__ void __launch_bounds__(256) stft_features_kernel(
         if (active && f0 + lf0 + j < T) {
             // bins 0..200 only: k = q + 20*k2 with k2 <= 9, plus k = 200 (q = 0, k2 = 10).  Straight from the
             // registers of pass 2: for a fixed k2 the 20 lanes of a frame write 20 consecutive floats.
-            const int64_t o = (fr_beg + f0 + lf0 + j) * kBins + q;
+            float* __restrict__ lo_ = logmag + (fr_beg + f0) * kBins;                // run base (uniform) + 32-bit offsets
+            float* __restrict__ po_ = phase ? phase + (fr_beg + f0) * kBins : nullptr;
+            const unsigned o = (unsigned)((lf0 + j) * kBins + q) * 4u;
 #pragma unroll
             for (int k2 = 0; k2 < 11; ++k2) {
                 if (k2 == 10 && q != 0) break;
                 const cplx v = X[k2];
                 const float mag = __builtin_amdgcn_sqrtf(v.x * v.x + v.y * v.y);
-                logmag[o + 20 * k2] = fast_log(mag + 1e-5f);
-                if (phase) phase[o + 20 * k2] = fast_atan2(v.y, v.x);
+                stg32(lo_, o + 80 * k2, fast_log(mag + 1e-5f));
+                if (po_) stg32(po_, o + 80 * k2, fast_atan2(v.y, v.x));
             }
         }
     }
@@ -205,6 +218,10 @@ __global__ void __launch_bounds__(256, 2) istft_ola_kernel(
         const int64_t fb_ = tab.frame_off[c];
         const int Tc = (int)(tab.frame_off[c + 1] - fb_);
         const int fr0 = block_h0[blk] - 2 + lf0;
+        // wave-uniform 64-bit base of the clip + 32-bit element offsets per lane (a clip is far below 2^31 / 201
+        // frames): the loads take the scalar-base form instead of a 64-bit address computation per element
+        const float* __restrict__ lmc = logmag + fb_ * kBins;
+        const float* __restrict__ phc = phase + fb_ * kBins;
         va = 0; vb = 0;
 #pragma unroll
         for (int u = 0; u < NIN; ++u) {
@@ -213,9 +230,9 @@ __global__ void __launch_bounds__(256, 2) istft_ola_kernel(
             const int fa = fr0 + 2 * tr;
             const bool oka = idx < kFpw * kBins && fa >= 0 && fa < Tc;
             const bool okb = idx < kFpw * kBins && fa + 1 >= 0 && fa + 1 < Tc;
-            const int64_t oa = oka ? (fb_ + fa) * kBins + k : 0, ob = okb ? (fb_ + fa + 1) * kBins + k : 0;
-            la[u] = logmag[oa]; pa[u] = phase[oa];
-            lb[u] = logmag[ob]; pb[u] = phase[ob];
+            const unsigned oa = oka ? (unsigned)(fa * kBins + k) * 4u : 0u, ob = okb ? (unsigned)((fa + 1) * kBins + k) * 4u : 0u;
+            la[u] = ldg32(lmc, oa); pa[u] = ldg32(phc, oa);
+            lb[u] = ldg32(lmc, ob); pb[u] = ldg32(phc, ob);
             va |= oka ? 1u << u : 0u;
             vb |= okb ? 1u << u : 0u;
         }
@@ -230,7 +247,7 @@ __global__ void __launch_bounds__(256, 2) istft_ola_kernel(
         const int clip = block_clip[blk], h0 = block_h0[blk];
         const int64_t fr_beg = tab.frame_off[clip];
         const int T = (int)(tab.frame_off[clip + 1] - fr_beg);
-        const int64_t nout = (int64_t)(T - 1) * kHop + kWin;
+        const int nout = (T - 1) * kHop + kWin;
         // Z = A + iB over all 400 bins from the 201 given ones (frames outside [0, T) contribute zero)
 #pragma unroll
         for (int u = 0; u < NIN; ++u) {
@@ -289,16 +306,16 @@ __global__ void __launch_bounds__(256, 2) istft_ola_kernel(
         }
         __syncthreads();
         // gather-form overlap-add: sample i of hop u sums frames u-2, u-1, u (ascending)
-        const int64_t obase = tab.out_off[clip];
+        float* __restrict__ wo = wav_out + tab.out_off[clip];    // uniform base + 32-bit sample position within the clip
         for (int i = tid; i < HB * kHop; i += 256) {
             const int hl = i / kHop, r = i - hl * kHop;
-            const int64_t pos = (int64_t)(h0 + hl) * kHop + r;
+            const int pos = (h0 + hl) * kHop + r;
             if (pos >= nout) break;
             float acc = 0.f;
             if (r < kWin - 2 * kHop) acc = y[hl * kWin + 2 * kHop + r];
             acc += y[(hl + 1) * kWin + kHop + r];
             acc += y[(hl + 2) * kWin + r];
-            wav_out[obase + pos] = acc;
+            stg32(wo, (unsigned)pos * 4u, acc);
         }
         __syncthreads();                             // y has been read: the areas may be rewritten
     }
