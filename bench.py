@@ -285,7 +285,10 @@ def main():
                               * v.get("dispatches_pass_c", 0) for v in rows) / n
                 traffic_src = PMC_SUMMARY + " (FETCH_SIZE x2 + WRITE_SIZE, bytes per conv launch)"
         gbs = lambda e: e["bytes"] / (e["ms"] * 1e-3) / 1e9 if e and e["ms"] > 0 else None
+        # stft_features = the mixture's STFT (log-magnitude + phase: the 2,248 B/frame of SURVEY 8d); the two
+        # context STFTs (200 frames per clip, log-magnitude only: 1,444 B/frame) are timed as their own entry
         stft_gbs, istft_gbs = gbs(prof.get("stft_features")), gbs(prof.get("istft_ola"))
+        stft_ctx_gbs = gbs(prof.get("stft_context_features"))
         step_flops = conv_fl + sum(v["flops"] for k, v in prof.items() if k.startswith("direct_conv"))
         line = {
             "metric": "denoised audio seconds per second (16 kHz), whole job",
@@ -326,7 +329,8 @@ def main():
                          "per_kernel": {k: {"ms": v["ms"], "launches": v["calls"],
                                             "tflops": v["flops"] / (v["ms"] * 1e-3) / 1e12 if v["ms"] > 0 else None}
                                         for k, v in sorted(convs.items())}},
-            "hbm_kernels": {"stft_features_GBs": stft_gbs, "istft_ola_GBs": istft_gbs, "peak_GBs": HBM_PEAK_GBS,
+            "hbm_kernels": {"stft_features_GBs": stft_gbs, "istft_ola_GBs": istft_gbs, "stft_context_features_GBs": stft_ctx_gbs,
+                            "peak_GBs": HBM_PEAK_GBS,
                             "achievable_GBs": HBM_ACHIEVABLE_GBS,
                             "stft_frac_of_achievable": stft_gbs / HBM_ACHIEVABLE_GBS if stft_gbs else None,
                             "istft_frac_of_achievable": istft_gbs / HBM_ACHIEVABLE_GBS if istft_gbs else None,

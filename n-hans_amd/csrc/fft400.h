@@ -103,6 +103,55 @@ template <bool INV> NH_HD void dft20(const cplx* in, cplx* out) {
     }
 }
 
+// 20-point FORWARD DFT of a REAL sequence, bins 0..10 only (the rest are their conjugates): the first pass of the
+// analysis transform.  Same 4 x 5 factorisation as dft20: n = 5*n1 + n2, k = k1 + 4*k2.  On real input the
+// radix-4 stage gives y[n2][0], y[n2][2] real and y[n2][3] = conj(y[n2][1]), so
+//   k1 = 0 : a real-input 5-point DFT            -> bins 0, 4, 8
+//   k1 = 2 : real values times W20^(2*n2)        -> bins 2, 6, 10
+//   k1 = 1 : the one full complex 5-point DFT    -> bins 1, 5, 9, 13, 17; bins 7 and 3 are conj(13), conj(17)
+// and the k1 = 3 branch is never computed.  Everything is written through the complex helpers with literal zero
+// imaginary parts; the compiler folds those and drops the unused outputs.
+NH_HD void rdft20_half(const float* in /*20 reals*/, cplx* out /*11: bins 0..10*/) {
+    const float C20[20] = NH_C20;
+    const float S20[20] = NH_S20;
+    float r0[5], r2[5];          // y[n2][0], y[n2][2] (real)
+    cplx c1[5];                  // y[n2][1]
+#pragma unroll
+    for (int n2 = 0; n2 < 5; ++n2) {
+        const float a = in[n2] + in[10 + n2], b = in[n2] - in[10 + n2];
+        const float c = in[5 + n2] + in[15 + n2], d = in[5 + n2] - in[15 + n2];
+        r0[n2] = a + c;
+        r2[n2] = a - c;
+        c1[n2] = cmake(b, -d);                                   // b - i d
+    }
+    // k1 = 0
+    {
+        cplx b0 = cmake(r0[0], 0.f), b1 = cmake(r0[1], 0.f), b2 = cmake(r0[2], 0.f), b3 = cmake(r0[3], 0.f), b4 = cmake(r0[4], 0.f);
+        dft5<false>(b0, b1, b2, b3, b4);
+        out[0] = b0; out[4] = b1; out[8] = b2;
+    }
+    // k1 = 2: twiddle W20^(2*n2) on a real value
+    {
+        cplx b[5];
+        b[0] = cmake(r2[0], 0.f);
+#pragma unroll
+        for (int n2 = 1; n2 < 5; ++n2) b[n2] = cmake(r2[n2] * C20[2 * n2], -r2[n2] * S20[2 * n2]);
+        dft5<false>(b[0], b[1], b[2], b[3], b[4]);
+        out[2] = b[0]; out[6] = b[1]; out[10] = b[2];
+    }
+    // k1 = 1: twiddle W20^(n2), full 5-point DFT
+    {
+        cplx b[5];
+        b[0] = c1[0];
+#pragma unroll
+        for (int n2 = 1; n2 < 5; ++n2) b[n2] = cmul(c1[n2], cmake(C20[n2], -S20[n2]));
+        dft5<false>(b[0], b[1], b[2], b[3], b[4]);
+        out[1] = b[0]; out[5] = b[1]; out[9] = b[2];
+        out[7] = cconj(b[3]);                                    // bin 13
+        out[3] = cconj(b[4]);                                    // bin 17
+    }
+}
+
 // The 400-point transform is two passes of 20-point DFTs around a 20x20 transpose:
 //   n = 20*n1 + n2, k = k1 + 20*k2
 //   pass 1 (one lane per n2): Y[k1] = DFT20_{n1}(x[20*n1 + n2]);  T[k1][n2] = Y[k1] * W400^(n2*k1)
@@ -118,6 +167,16 @@ template <bool INV> NH_HD void fft400_pass1(const cplx* col /*20, n1-major*/, in
         if (INV) w = cconj(w);
         out[k1] = cmul(y[k1], w);
     }
+}
+
+// Pass 1 of the ANALYSIS transform of a real frame: rows k1 = 0..10 only.  Pass 2 on those rows yields every bin
+// k1 + 20*k2; the bins of rows 11..19 below 201 are the conjugates of bins 400-k of rows 1..9.
+NH_HD void fft400_pass1_real(const float* col /*20 reals, n1-major*/, int n2, const cplx* tw400, cplx* out /*11, by k1*/) {
+    cplx y[11];
+    rdft20_half(col, y);
+    out[0] = y[0];
+#pragma unroll
+    for (int k1 = 1; k1 < 11; ++k1) out[k1] = cmul(y[k1], tw400[n2 * k1]);
 }
 
 template <bool INV> NH_HD void fft400_pass2(const cplx* row /*20, by n2*/, cplx* out /*20, by k2*/) {

@@ -490,7 +490,7 @@ int stft_impl(nhans_ctx* c, const float* wav, const int64_t* soff, int nclips, i
     rc = h2d(c, dev_blocks, bclip.data(), (size_t)nb * 4, s); if (rc) return rc;
     rc = h2d(c, dev_blocks + nb, bf0.data(), (size_t)nb * 4, s); if (rc) return rc;
     ClipTable t{dev_tables, dev_tables + (nclips + 1), nullptr};
-    Prof pr(c, s, "stft_features");
+    Prof pr(c, s, phase ? "stft_features" : "stft_context_features");   // (contexts: log-magnitude only, 200 frames per clip)
     launch_stft(wav, t, dev_blocks, dev_blocks + nb, nb, c->A("tw400"), c->A("window"), logmag, phase, s);
     pr.done(0, (double)foff[nclips] * (kHop * 4 + (phase ? 2 : 1) * kBins * 4));
     if (foff_out) *foff_out = foff;

@@ -187,7 +187,7 @@ void launch_stft(const float* wav, ClipTable t, const int* block_clip, const int
 void launch_istft(const float* logmag, const float* phase, ClipTable t, const int* block_clip,
                   const int* block_h0, int nblocks, const float* tw400, const float* wsyn /*400*/,
                   float* wav_out, hipStream_t s);
-constexpr int kStftFramesPerBlock = 24;   // 4 waves x 3 frames x 2 passes
+constexpr int kStftFramesPerBlock = 23;   // frames per run: 460 pass-1 tasks (256 + 204) and 253 pass-2 tasks on 256 lanes
 constexpr int kIstftHopsPerBlock = 22;    // output hops per block; needs 24 frames
 
 }  // namespace nhans

@@ -84,11 +84,18 @@ __device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// The ANALYSIS transform stays one real frame per complex transform: packing two frames (z = a + i b, untangled as
-// A = (Z[k] + conj Z[400-k]) / 2) leaks float32 rounding of the louder frame into the quieter one, and
-// log(|X| + 1e-5) amplifies that at silent bins -- measured as 1.25e-4 instead of 7e-5 on the context embeddings of
-// the separator test, past the 1e-4 bar, for 8 % of a kernel that is 0.01 % of a step.  The inverse transform
-// (below) does pack two frames: there the leak is 1e-7 of a waveform sample.
+// The ANALYSIS transform is one real frame per transform, but a REAL one: pass 1 computes rows k1 = 0..10 of the
+// 20 x 20 decomposition from real columns (fft400.h: rdft20_half -- the conjugate-symmetric half, with the k1 = 3
+// radix-5 branch never computed), pass 2 runs full complex 20-point DFTs on those 11 rows only, and a row's
+// outputs k2 >= 10 are written as the conjugates of bins 400 - k (rows 1..9), which covers rows 11..19.  460
+// pass-1 tasks and 253 pass-2 tasks per run of 23 frames, spread over the workgroup's 256 lanes.
+// (Packing TWO frames into one complex transform, z = a + i b untangled as A = (Z[k] + conj Z[400-k]) / 2, was
+// built and taken out: it leaks float32 rounding of the louder frame into the quieter one, log(|X| + 1e-5)
+// amplifies that at silent bins -- 1.25e-4 instead of 7e-5 on the separator's context embeddings, past the 1e-4
+// bar.  The inverse transform below does pack two frames: there the leak is 1e-7 of a waveform sample.)
+constexpr int kRows = 11;                    // rows k1 = 0..10 of the transposed intermediate
+constexpr int kTReal = kRows * kTRow;        // 231 complex per frame
+
 __global__ void __launch_bounds__(256) stft_features_kernel(
     const float* __restrict__ wav, ClipTable tab, const int* __restrict__ block_clip,
     const int* __restrict__ block_f0, int nblocks, const cplx* __restrict__ tw400g, const float* __restrict__ windowg,
@@ -98,9 +105,9 @@ __global__ void __launch_bounds__(256) stft_features_kernel(
     __shared__ __attribute__((aligned(16))) float xs[SPAN];
     __shared__ float win[kWin];
     __shared__ cplx tw[400];
-    __shared__ cplx tbuf[4 * kFpw * kTFrame];      // transpose buffer; spectrum rows alias it per wave
+    __shared__ cplx tbuf[F * kTReal];              // T[frame][k1][n2], rows padded to 21
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x;
     constexpr int NPRE = (SPAN + 255) / 256;        // samples per thread of one run
     float pre[NPRE];
     auto fetch = [&](int blk) {                     // the run's samples -> registers (loads stay in flight)
@@ -117,10 +124,6 @@ __global__ void __launch_bounds__(256) stft_features_kernel(
     for (int i = tid; i < 400; i += 256) { tw[i] = tw400g[i]; win[i] = windowg[i]; }
     fetch(blockIdx.x);
 
-    const int j = lane / 20, q = lane - j * 20;     // frame slot within the wave, DFT column/row
-    const bool active = lane < 60;
-    cplx* tw_wave = tbuf + wave * kFpw * kTFrame;
-
 #pragma unroll 1
   for (int blk = blockIdx.x; blk < nblocks; blk += gridDim.x) {
     const int clip = block_clip[blk], f0 = block_f0[blk];
@@ -131,47 +134,47 @@ __global__ void __launch_bounds__(256) stft_features_kernel(
         const int i = u * 256 + tid;
         if (i < SPAN) xs[i] = pre[u];
     }
-    __syncthreads();                                // (also: the previous run's last pass is through with tbuf)
+    __syncthreads();                                // (also: every lane is through with the previous run's rows)
     if (blk + (int)gridDim.x < nblocks) fetch(blk + gridDim.x);
 
+    // pass 1: task (frame f, column n2) = real 20-point DFT over n1 of the windowed samples x[20*n1 + n2]
 #pragma unroll 1
-    for (int p = 0; p < F / (4 * kFpw); ++p) {
-        const int lf0 = p * 4 * kFpw + wave * kFpw;  // first local frame of this wave
-        if (active) {
-            // pass 1: lane = n2; 20-point DFT over n1 of the windowed samples x[20*n1 + n2]
-            cplx col[20], y[20];
-            const float* xf = xs + (lf0 + j) * kHop;
+    for (int id = tid; id < F * 20; id += 256) {
+        const int f = id / 20, n2 = id - f * 20;
+        float col[20];
+        cplx y[kRows];
+        const float* xf = xs + f * kHop + n2;
 #pragma unroll
-            for (int n1 = 0; n1 < 20; ++n1) col[n1] = cmake(xf[20 * n1 + q] * win[20 * n1 + q], 0.f);
-            fft400_pass1<false>(col, q, tw, y);
-            cplx* tf = tw_wave + j * kTFrame;
+        for (int n1 = 0; n1 < 20; ++n1) col[n1] = xf[20 * n1] * win[20 * n1 + n2];
+        fft400_pass1_real(col, n2, tw, y);
+        cplx* tf = tbuf + f * kTReal + n2;
 #pragma unroll
-            for (int k1 = 0; k1 < 20; ++k1) tf[k1 * kTRow + q] = y[k1];
-        }
-        __syncthreads();
-        cplx X[20];
-        if (active) {
-            // pass 2: lane = k1; 20-point DFT over n2 -> X[k1 + 20*k2]
-            cplx row[20];
-            const cplx* tf = tw_wave + j * kTFrame + q * kTRow;
+        for (int k1 = 0; k1 < kRows; ++k1) tf[k1 * kTRow] = y[k1];
+    }
+    __syncthreads();
+    // pass 2: task (frame f, row k1 <= 10) = complex 20-point DFT over n2 -> X[k1 + 20*k2], k2 = 0..19
+    if (tid < F * kRows) {
+        const int f = tid / kRows, k1 = tid - f * kRows;
+        cplx row[20], X[20];
+        const cplx* tf = tbuf + f * kTReal + k1 * kTRow;
 #pragma unroll
-            for (int n2 = 0; n2 < 20; ++n2) row[n2] = tf[n2];
-            fft400_pass2<false>(row, X);
-        }
-        __syncthreads();                            // every lane has its row: the transpose buffer is free again
-        if (active && f0 + lf0 + j < T) {
-            // bins 0..200 only: k = q + 20*k2 with k2 <= 9, plus k = 200 (q = 0, k2 = 10).  Straight from the
-            // registers of pass 2: for a fixed k2 the 20 lanes of a frame write 20 consecutive floats.
-            float* __restrict__ lo_ = logmag + (fr_beg + f0) * kBins;                // run base (uniform) + 32-bit offsets
-            float* __restrict__ po_ = phase ? phase + (fr_beg + f0) * kBins : nullptr;
-            const unsigned o = (unsigned)((lf0 + j) * kBins + q) * 4u;
+        for (int n2 = 0; n2 < 20; ++n2) row[n2] = tf[n2];
+        fft400_pass2<false>(row, X);
+        if (f0 + f < T) {
+            float* __restrict__ lo_ = logmag + (fr_beg + f0 + f) * kBins;         // the frame's row (64-bit once per lane)
+            float* __restrict__ po_ = phase ? phase + (fr_beg + f0 + f) * kBins : nullptr;
+            // k2 < 10: bin k1 + 20*k2 as computed.  k2 >= 10: bin 400 - (k1 + 20*k2) as the conjugate (rows 1..9);
+            // row 0 has the Nyquist bin 200 at k2 = 10 and nothing else there, row 10 nothing.
 #pragma unroll
-            for (int k2 = 0; k2 < 11; ++k2) {
-                if (k2 == 10 && q != 0) break;
+            for (int k2 = 0; k2 < 20; ++k2) {
+                const bool mirror = k2 >= 10 && k1 != 0;
+                const bool live = k2 < 10 || (k1 == 0 ? k2 == 10 : k1 != 10);
+                if (!live) continue;
+                const int bin = mirror ? 400 - k1 - 20 * k2 : k1 + 20 * k2;
                 const cplx v = X[k2];
                 const float mag = __builtin_amdgcn_sqrtf(v.x * v.x + v.y * v.y);
-                stg32(lo_, o + 80 * k2, fast_log(mag + 1e-5f));
-                if (po_) stg32(po_, o + 80 * k2, fast_atan2(v.y, v.x));
+                lo_[bin] = fast_log(mag + 1e-5f);
+                if (po_) po_[bin] = fast_atan2(mirror ? -v.y : v.y, v.x);
             }
         }
     }
@@ -181,7 +184,8 @@ __global__ void __launch_bounds__(256) stft_features_kernel(
 void launch_stft(const float* wav, ClipTable t, const int* block_clip, const int* block_f0, int nblocks,
                  const float* tw400, const float* window, float* logmag, float* phase, hipStream_t s) {
     if (nblocks <= 0) return;
-    const int grid = nblocks < (256 * 2) ? nblocks : (256 * 2);
+    constexpr int wg_per_cu = kStftFramesPerBlock <= 19 ? 3 : 2;            // resident workgroups (LDS: 53 KB at 19 frames)
+    const int grid = nblocks < (256 * wg_per_cu) ? nblocks : (256 * wg_per_cu);
     NHANS_LAUNCH("stft_features", stft_features_kernel, dim3(grid), dim3(256), 0, s, wav, t, block_clip, block_f0, nblocks,
                  reinterpret_cast<const cplx*>(tw400), window, logmag, phase);
 }

@@ -297,6 +297,12 @@ def test_fft400_host_build_matches_numpy(tmp_path):
         lib.nhans_fft400_host(x.ctypes.data_as(ctypes.c_void_p), out.ctypes.data_as(ctypes.c_void_p), inv)
         ref = np.fft.ifft(x.astype(np.complex128)) * 400 if inv else np.fft.fft(x.astype(np.complex128))
         assert np.abs(out - ref).max() < 5e-6 * np.abs(ref).max()
+    # the real-input analysis transform of the STFT kernel (rows 0..10 + conjugate mirror) against numpy's rfft
+    xr = rng.standard_normal(400).astype(np.float32)
+    outr = np.full(201, np.nan + 0j, np.complex64)
+    lib.nhans_rfft400_host(xr.ctypes.data_as(ctypes.c_void_p), outr.ctypes.data_as(ctypes.c_void_p))
+    refr = np.fft.rfft(xr.astype(np.float64))
+    assert np.isfinite(outr).all() and np.abs(outr - refr).max() < 5e-6 * np.abs(refr).max()
 
 
 def test_synthetic_audio_is_deterministic():
