@@ -311,15 +311,31 @@ __global__ void __launch_bounds__(256, 2) istft_ola_kernel(
         __syncthreads();
         // gather-form overlap-add: sample i of hop u sums frames u-2, u-1, u (ascending)
         float* __restrict__ wo = wav_out + tab.out_off[clip];    // uniform base + 32-bit sample position within the clip
-        for (int i = tid; i < HB * kHop; i += 256) {
-            const int hl = i / kHop, r = i - hl * kHop;
-            const int pos = (h0 + hl) * kHop + r;
-            if (pos >= nout) break;
-            float acc = 0.f;
-            if (r < kWin - 2 * kHop) acc = y[hl * kWin + 2 * kHop + r];
-            acc += y[(hl + 1) * kWin + kHop + r];
-            acc += y[(hl + 2) * kWin + r];
-            stg32(wo, (unsigned)pos * 4u, acc);
+        if ((reinterpret_cast<uintptr_t>(wo) & 15) == 0) {
+            // four consecutive samples per lane (hop, window and the 80-sample head are multiples of 4, and a clip's
+            // length is too): 16-byte LDS reads and global stores, the same three-term sum per sample
+            typedef float f32x4v __attribute__((ext_vector_type(4)));
+            for (int i = tid * 4; i < HB * kHop; i += 1024) {
+                const int hl = i / kHop, r = i - hl * kHop;
+                const int pos = (h0 + hl) * kHop + r;
+                if (pos >= nout) break;
+                f32x4v acc = {0.f, 0.f, 0.f, 0.f};
+                if (r < kWin - 2 * kHop) acc = *reinterpret_cast<const f32x4v*>(y + hl * kWin + 2 * kHop + r);
+                acc += *reinterpret_cast<const f32x4v*>(y + (hl + 1) * kWin + kHop + r);
+                acc += *reinterpret_cast<const f32x4v*>(y + (hl + 2) * kWin + r);
+                *reinterpret_cast<f32x4v*>(reinterpret_cast<char*>(wo) + (unsigned)pos * 4u) = acc;
+            }
+        } else {                                     // an output offset the caller did not align to 16 bytes
+            for (int i = tid; i < HB * kHop; i += 256) {
+                const int hl = i / kHop, r = i - hl * kHop;
+                const int pos = (h0 + hl) * kHop + r;
+                if (pos >= nout) break;
+                float acc = 0.f;
+                if (r < kWin - 2 * kHop) acc = y[hl * kWin + 2 * kHop + r];
+                acc += y[(hl + 1) * kWin + kHop + r];
+                acc += y[(hl + 2) * kWin + r];
+                stg32(wo, (unsigned)pos * 4u, acc);
+            }
         }
         __syncthreads();                             // y has been read: the areas may be rewritten
     }

@@ -115,3 +115,23 @@ def test_two_contexts_of_both_models_interleaved(lib_built, weights_denoiser, we
     finally:
         ed.close()
         es.close()
+
+
+def test_istft_output_not_aligned_to_16_bytes(eng):
+    """The inverse STFT stores four samples per lane when the clip's output starts on a 16-byte boundary and falls back
+    to single stores otherwise (a foreign caller may hand over any float offset): both paths, same bits."""
+    mixes, _, _ = _batch(640, (0.7, 0.025, 0.31))
+    wav, off = eng._dev(mixes)
+    lm, ph = eng.stft_features(wav, off)
+    foff = [0]
+    for m in mixes:
+        foff.append(foff[-1] + spec.frames_for_samples(len(m))[1])
+    ref, ooff = eng.istft(lm, ph, foff)
+    for shift in (1, 2, 3):
+        buf = torch.full((ooff[-1] + 8,), 9.0, dtype=torch.float32, device="cuda")
+        view = buf[shift:]                                      # same offsets, base pointer moved by `shift` floats
+        hip.check(eng.lib.nhans_istft(eng.handle, hip.ptr(lm), hip.ptr(ph), hip.i64_array(foff), len(mixes),
+                                      hip.i64_array(ooff), ctypes.c_void_p(view.data_ptr()), eng._stream()))
+        torch.cuda.synchronize()
+        assert torch.equal(view[:ooff[-1]], ref), shift
+        assert float(buf[:shift].min()) == 9.0 and float(buf[shift + ooff[-1]:].min()) == 9.0     # nothing outside
