@@ -7,25 +7,27 @@
 //                          window_fn=inverse_stft_window_fn(160, hann periodic))   (SN/apply.py:189-204)
 //
 // Both are HBM-bound by their algorithmic bytes (2,248 per frame) and VALU-instruction-bound in practice.
-// The 400-point transform is 20 x 20 (fft400.h): every lane computes one 20-point DFT in registers, and the
-// 20x20 transpose between the two passes goes through LDS rows padded to 21 complex values.  Workgroups are
-// persistent and walk the list of 24-frame runs of the batch.
-//   STFT: one frame per transform, 3 frames per wavefront, two passes of 12 frames per run; the run's sample
-//   span is staged in LDS once (each sample crosses HBM once although it is in 2.5 frames) and the NEXT run's
-//   samples are fetched into registers before the current run is transformed; the bins are written straight from
-//   the registers of the second pass.
+// The 400-point transform is 20 x 20 (fft400.h): a lane computes one 20-point DFT in registers, and the 20 x 20
+// transpose between the two passes goes through LDS rows padded to 21 complex values.  Complex values are native
+// 2-vectors (packed-f32 math), global accesses are a wave-uniform base plus a 32-bit byte offset per lane, and
+// workgroups are persistent: they walk the list of runs of the batch.
+//   STFT: runs of 23 frames; the run's sample span is staged in LDS once (each sample crosses HBM once although
+//   it is in 2.5 frames) and the NEXT run's samples are fetched into registers before the current run is
+//   transformed.  The transform is REAL-input: pass 1 (460 tasks = frame x column, dealt to all 256 lanes)
+//   computes rows 0..10 only, pass 2 (253 tasks = frame x row) runs complex DFTs on those and stores its outputs
+//   k2 >= 10 as the conjugates of bins 400 - k; the bins are written straight from the pass-2 registers.
 //   iSTFT: TWO frames share one complex transform (Z = A + iB), 3 transforms = 6 frames per wavefront, one pass
-//   of 24 frames per run; the next run's log-magnitudes and phases are fetched into registers before the current
-//   run is transformed; the windowed frames land in an LDS buffer that aliases the (wavefront-private) transform
-//   areas; overlap-add is in gather form (each output sample summed by one thread from its <= 3 frames in
-//   ascending order: no atomics, bitwise deterministic).
+//   of 24 frames per run at two waves per SIMD; the next run's log-magnitudes and phases are fetched into
+//   registers before the current run is transformed; the windowed frames land in an LDS buffer that aliases the
+//   (wavefront-private) transform areas; overlap-add is in gather form (each output sample summed from its <= 3
+//   frames in ascending order, four samples per lane: no atomics, bitwise deterministic).
 // log/atan2/exp/sincos run on the hardware transcendental units (below).
 #include "nhans_kernels.h"
 #include "fft400.h"
 
 namespace nhans {
 
-constexpr int kFpw = 3;                 // frames per wavefront per pass
+constexpr int kFpw = 3;                 // iSTFT: transforms per wavefront
 constexpr int kTRow = 21;               // padded transpose row (complex values)
 constexpr int kTFrame = 20 * kTRow;     // 420 complex per frame
 // ---- feature math on the hardware transcendental units.  Both kernels are VALU-bound once their loads
