@@ -29,7 +29,9 @@
  * Ragged batches: clip c owns samples [sample_offsets[c], sample_offsets[c+1]) of the wav
  * buffer and frames [frame_offsets[c], frame_offsets[c+1]) of every [T_total, 201] tensor, with
  * T_c = nhans_num_frames(n_c) = 1 + (n_c - 400) / 160 for n_c >= 400 (the caller has already
- * applied the reference's normalise + tail-trim, SN/apply.py:150-161).
+ * applied the reference's normalise + tail-trim, SN/apply.py:150-161).  A batch may hold any number of
+ * frames (64-bit offsets between clips); ONE clip is limited to 5,000,000 frames (13.9 hours: offsets inside a
+ * clip are 32-bit) and a longer one is refused with NHANS_EINVAL.
  */
 #ifndef NHANS_HIP_H
 #define NHANS_HIP_H

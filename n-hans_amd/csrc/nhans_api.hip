@@ -476,6 +476,8 @@ int stft_impl(nhans_ctx* c, const float* wav, const int64_t* soff, int nclips, i
     std::vector<int> bclip, bf0;
     for (int i = 0; i < nclips; ++i) {
         int64_t t = nhans_num_frames(soff[i + 1] - soff[i]);
+        if (t > kMaxFramesPerClip) return fail(NHANS_EINVAL, "clip " + std::to_string(i) + " has more than " +
+                                               std::to_string(kMaxFramesPerClip) + " frames (32-bit offsets within a clip)");
         if (maxf > 0) {
             if (t < maxf) return fail(NHANS_ESHORT, "conditioning clip " + std::to_string(i) + " has " +
                                       std::to_string(t) + " frames; " + std::to_string(maxf) + " needed");
@@ -512,6 +514,8 @@ int istft_impl(nhans_ctx* c, const float* logmag, const float* phase, const int6
     std::vector<int> bclip, bh0;
     for (int i = 0; i < nclips; ++i) {
         const int64_t t = foff[i + 1] - foff[i];
+        if (t > kMaxFramesPerClip) return fail(NHANS_EINVAL, "clip " + std::to_string(i) + " has more than " +
+                                               std::to_string(kMaxFramesPerClip) + " frames (32-bit offsets within a clip)");
         if (t <= 0) continue;
         for (int h0 = 0; h0 < t + 2; h0 += kIstftHopsPerBlock) { bclip.push_back(i); bh0.push_back(h0); }
     }

@@ -188,6 +188,7 @@ void launch_istft(const float* logmag, const float* phase, ClipTable t, const in
                   const int* block_h0, int nblocks, const float* tw400, const float* wsyn /*400*/,
                   float* wav_out, hipStream_t s);
 constexpr int kStftFramesPerBlock = 23;   // frames per run: 460 pass-1 tasks (256 + 204) and 253 pass-2 tasks on 256 lanes
+constexpr int64_t kMaxFramesPerClip = 5000000;   // 13.9 h: the STFT / iSTFT kernels address a clip with 32-bit byte offsets
 constexpr int kIstftHopsPerBlock = 22;    // output hops per block; needs 24 frames
 
 }  // namespace nhans

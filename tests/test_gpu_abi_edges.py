@@ -135,3 +135,24 @@ def test_istft_output_not_aligned_to_16_bytes(eng):
         torch.cuda.synchronize()
         assert torch.equal(view[:ooff[-1]], ref), shift
         assert float(buf[:shift].min()) == 9.0 and float(buf[shift + ooff[-1]:].min()) == 9.0     # nothing outside
+
+
+def test_ten_minute_clip_and_the_per_clip_frame_limit(eng):
+    """One long clip (10 minutes = 59,998 frames, 16 chunks of frame windows): finite, unsaturated, and 100 frames from
+    its middle bit-equal to the same frames run through the stage-level mask_net from the same features and
+    embeddings.  A clip beyond 5,000,000 frames (32-bit offsets inside a clip) is refused before anything is launched."""
+    rng = np.random.default_rng(5)
+    n = 400 + 160 * 59997
+    mix = (0.1 * rng.standard_normal(n)).astype(np.float32)
+    ca, cb = apply.normalise(synth.noise_context(650)), apply.normalise(synth.speaker_context(651))
+    out = eng.enhance([mix], [ca], [cb], want_mixed=False, taps=True)
+    assert out["logits"].shape == (59998, 201) and np.isfinite(out["logits"]).all() and np.isfinite(out["denoised_wav"][0]).all()
+    assert eng.take_status() == 0
+    lm = torch.from_numpy(out["logmag"][29900:30200].copy()).cuda()
+    emb = torch.from_numpy(out["emb"]).cuda()
+    lg, _ = eng.mask_net(lm, [0, 300], emb[0:1], emb[1:2])
+    assert np.array_equal(lg.cpu().numpy()[100:200], out["logits"][30000:30100])
+    off = hip.i64_array([0, 400 + 160 * 5000000])
+    rc = eng.lib.nhans_stft_features(eng.handle, hip.ptr(torch.zeros(8, device="cuda")), off, 1, 0,
+                                     hip.ptr(torch.zeros(8, device="cuda")), None, None)
+    assert rc == -1 and b"5000000" in eng.lib.nhans_last_error()
