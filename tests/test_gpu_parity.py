@@ -10,7 +10,7 @@ import pytest
 import torch
 
 import nhans_amd  # noqa: F401
-from nhans_amd import apply, engine, spec, synth
+from nhans_amd import apply, engine, synth
 from oracle import nhans_oracle as O
 from conftest import GOLDEN, load_case
 
