@@ -92,8 +92,9 @@ void nhans_destroy(nhans_ctx* ctx);
  *           64-channel convs on 2-D 256-pixel tiles -- same results within rounding, different speed).
  *          "epilogue_wide" (1, default: split-f16 epilogues move 8 channels = 16-byte pieces per thread;
  *           0: 4 channels -- identical bits, kept for A/B),
- *          "consumer_interleave" (1, default: the MFMA waves of the halo kernels issue their LDS operand
- *           reads between their MFMAs; 0: read block then MFMA block -- identical bits, kept for A/B),
+ *          "consumer_interleave" (1, default: the MFMA waves of the halo kernel issue their LDS operand
+ *           reads between their MFMAs, one behind each of the first MFMAs of a half-tap; 2: spread evenly over the
+ *           half-tap; 0: read block then MFMA block -- identical bits, kept for A/B),
  *          "persistent_tiles" (0, default; 1: launches with >= 2 tiles per CU run the halo kernels as persistent
  *           workgroups whose DMA pipeline runs on across tile boundaries -- identical bits, measured 2-3 %
  *           slower, kept so that the measurement can be repeated),

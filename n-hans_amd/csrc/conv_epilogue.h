@@ -33,6 +33,21 @@ template <int I, int NM, int ND> __device__ __forceinline__ void pin_reads_betwe
     }
 }
 
+// The same reads FRONT-LOADED: one read after each of the first ND MFMAs of the half, then NM - ND MFMAs with nothing
+// behind them -- the last reads' LDS latency is covered by those MFMAs instead of showing at the lgkmcnt(0) in front of
+// the barrier between the halves.  What conv_igemm_halo.hip uses (+1 % wall time over the even spread, which stays
+// selectable); the kernels without a barrier between the halves measure the same or slightly worse with it and keep
+// the even spread; two reads behind each of the first four MFMAs is worse (-2.6 %).
+template <int I, int NM, int ND> __device__ __forceinline__ void pin_reads_front_loaded() {
+    if constexpr (I < ND) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        pin_reads_front_loaded<I + 1, NM, ND>();
+    } else if constexpr (NM > ND) {
+        __builtin_amdgcn_sched_group_barrier(0x008, NM - ND, 0);
+    }
+}
+
 // The epilogue's arithmetic, spelled out so that every kernel variant rounds alike (whether the compiler
 // contracts a*b+c into an fma depends on the surrounding code; a layer must give the same bits whichever
 // variant its launch size selects):  v = fma(acc, ws, cb) + tf;  v = fma(idw, residual, v).

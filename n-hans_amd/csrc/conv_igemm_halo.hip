@@ -347,7 +347,9 @@ __global__ void __launch_bounds__((NCW + NPW) * 64) conv_igemm_halo(const ConvAr
     // barrier (the producers have seen the operands of tap it+1 land, every consumer holds all of
     // tap it in registers -- which frees its weight stage and, after the last tap of a super-chunk, its
     // halo buffer); MFMAs of half 1 with the reads of half 0 of tap it+1 between them.
-    // The interleave is pinned (sched_group_barrier: NM/ND MFMAs, one ds_read, ...).  With a read block
+    // The interleave is pinned (sched_group_barrier): one ds_read behind each of the first ND MFMAs of the half,
+    // the remaining MFMAs with nothing behind them, so that the last reads have landed when the wave reaches the
+    // lgkmcnt(0) in front of the barrier (an even spread leaves the last read right there: +1 % wall).  With a read block
     // in front of an MFMA block -- the round-1 arrangement -- all eight waves hammer the LDS while the
     // matrix pipes idle and then the reverse; a wave's reads issued in the shadow of its own 32-cycle
     // MFMAs cost the pipe nothing (tools/ubench/fat_loop.hip: 2,436 -> 2,069 cycles per tap beside
@@ -359,7 +361,8 @@ __global__ void __launch_bounds__((NCW + NPW) * 64) conv_igemm_halo(const ConvAr
     constexpr int ND = KH_ * (TM + TN) * (PREC == 1 ? 2 : 1);       // ds_read_b128 per half
     static_assert(NM >= ND, "interleave pattern");
 #define NH_PIN_INTERLEAVE()                                                                        \
-    if constexpr (!(ABL & (16 | 32 | 128))) pin_reads_between_mfmas<0, NM, ND>();
+    if constexpr ((ABL & 256) != 0) pin_reads_between_mfmas<0, NM, ND>();                             \
+    else if constexpr (!(ABL & (16 | 32 | 128))) pin_reads_front_loaded<0, NM, ND>();
     NH_READ_HALF(0, 0)
     int stC = 0;                                        // ring stage of tap `it`
     for (int it = 0; it < total; ++it) {
@@ -473,6 +476,12 @@ void launch_conv_igemm_halo(const ConvArgs& a0, hipStream_t s) {
     ConvArgs a = a0;
     a.fdWP = make_fastdiv((uint32_t)(a.Wo + a.seg[0].KW - 1));
     const bool wide = a.N % 128 == 0;
+    if (a.ilv == 2 && a.prec == 1) {                    // A/B knob: operand reads spread evenly over the half (round 2's first pattern)
+        if (!wide && halo_tile_pixels(a) == 512) launch_halo_t<64, 1, 512, 0, 256>(a, s);
+        else if (wide) launch_halo_t<128, 1, 256, 0, 256>(a, s);
+        else launch_halo_t<64, 1, 256, 0, 256>(a, s);
+        return;
+    }
     if (!a.ilv && a.prec == 1) {                        // A/B knob: round-1 instruction order
         if (!wide && halo_tile_pixels(a) == 512) launch_halo_t<64, 1, 512, 0, 128>(a, s);
         else if (wide) launch_halo_t<128, 1, 256, 0, 128>(a, s);

@@ -706,7 +706,10 @@ int nhans_set_option(nhans_ctx* c, const char* key, int64_t value) {
         c->dbg = reinterpret_cast<long long*>(static_cast<intptr_t>(value));
     }
     else if (k == "epilogue_wide") c->epi8 = value != 0;
-    else if (k == "consumer_interleave") c->ilv = value != 0;
+    else if (k == "consumer_interleave") {
+        if (value < 0 || value > 2) return fail(NHANS_EINVAL, "consumer_interleave must be 0, 1 or 2");
+        c->ilv = (int)value;
+    }
     else if (k == "persistent_tiles") c->persist = value != 0;
     else if (k == "quad_workgroups") c->quad = value != 0;
     else if (k == "conv_variant") {

@@ -106,8 +106,8 @@ struct ConvArgs {
                            // 2, 3: LDS-DMA kernel with halo reuse across the KW taps where the conv allows it
     int epi8;              // split-NHWC outputs: 8 channels per thread in the epilogue sweep (16-byte pieces), default;
                            // 0 = the 4-channel sweep (A/B and parity cross-check; same bits)
-    int ilv;               // halo kernels: operand reads interleaved between the MFMAs (default 1); 0 = read block
-                           // then MFMA block (the round-1 order; A/B knob, same bits)
+    int ilv;               // halo kernel: operand reads between the MFMAs, front-loaded in each half (default 1); 2 = spread
+                           // evenly over the half; 0 = read block then MFMA block (the round-1 order) -- A/B knob, same bits
     int persist;           // halo kernels: persistent workgroups walking several tiles with the DMA pipeline kept
                            // running across tile boundaries (conv_igemm_halop.hip) when the launch has >= 2 tiles
                            // per CU (default 0: measured 2-3 % slower than one tile per workgroup; same bits)

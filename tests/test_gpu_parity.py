@@ -177,7 +177,7 @@ def test_mask_net_is_bitwise_reproducible(eng_d):
         assert torch.equal(first, again)
 
 
-@pytest.mark.parametrize("option, values", [("persistent_tiles", (1, 0)), ("consumer_interleave", (0, 1)),
+@pytest.mark.parametrize("option, values", [("persistent_tiles", (1, 0)), ("consumer_interleave", (0, 1)), ("consumer_interleave", (2, 1)),
                                             ("epilogue_wide", (0, 1)), ("conv_variant", (3, -1)),
                                             ("quad_workgroups", (1, 0))])
 def test_speed_knobs_do_not_change_a_bit(_eng_d, option, values):

@@ -54,7 +54,7 @@ def main():
             variant = int(rng.choice([-1, -1, 0, 1, 2, 3]))
             refs = [reference(prec, variant, i) for i in ids]
             fpc = int(rng.choice([1, 7, 33, 100, 257, 1024, 3776]))
-            cfg = {k: int(rng.integers(0, 2)) for k in knobs}
+            cfg = {k: int(rng.integers(0, 3 if k == "consumer_interleave" else 2)) for k in knobs}
             cfg["contexts_per_chunk"] = int(rng.choice([1, 3, 5, 64]))      # tower passes with a remainder chunk
             eng.set_precision(prec)
             eng.set_option("conv_variant", variant)
