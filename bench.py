@@ -18,27 +18,36 @@ region with hipEvents recorded by the library on the launch stream around every 
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
-import numpy as np
-import torch
-
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-import nhans_amd  # noqa: E402,F401
-from nhans_amd import engine, spec, synth, weights  # noqa: E402
-from nhans_amd.apply import normalise, trim_to_frames  # noqa: E402
+# torch, numpy and the package are imported by _rank_imports() in the processes that compute: the
+# launcher below (plain `python bench.py --gpus N`, N > 1) starts the ranks as child processes and
+# must never have loaded anything that could initialise the GPU.
+np = torch = engine = spec = synth = weights = normalise = trim_to_frames = None
+
+
+def _rank_imports():
+    global np, torch, engine, spec, synth, weights, normalise, trim_to_frames
+    import numpy as np
+    import torch
+    import nhans_amd  # noqa: F401
+    from nhans_amd import engine, spec, synth, weights
+    from nhans_amd.apply import normalise, trim_to_frames
 
 F32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 F16_MFMA_PEAK_TFLOPS = 2500.0     # dense f16 MFMA peak; the split mode executes 3 products per MAC
-F16_MFMA_AT_POWER_CAP_TFLOPS = 1660.0   # measured: register-only f16 MFMA loop, random operands, 1,400 W cap (profiles/r02)
+F16_MFMA_AT_POWER_CAP_TFLOPS = 1660.0   # round-2 measurement on another box (profiles/r02); reported only as a fallback when
+                                        # --no-ceiling skips the live measurement (nhans_debug_mfma_ceiling) on THIS box
 HBM_PEAK_GBS = 8000.0             # spec; 6,290 GB/s is what a float4 copy achieves (same guide)
 HBM_ACHIEVABLE_GBS = 6290.0
 PMC_SUMMARY = os.path.join("profiles", "r02", "pmc_summary_bench_256clips.json")
 
 
-def parse():
+def parse(argv=None):
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=3)
@@ -54,6 +63,9 @@ def parse():
                    help="nhans_set_option knob for an A/B run (e.g. quad_workgroups=1); recorded in config")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-kernel-pass", action="store_true", help="skip the extra profiled pass (rocprofv3 runs)")
+    p.add_argument("--ceiling-seconds", type=float, default=2.0,
+                   help="length of the register-only f16 MFMA run that measures this box's rate at its power cap")
+    p.add_argument("--no-ceiling", action="store_true", help="skip that measurement (quote the round-2 constant)")
     p.add_argument("--cpu-frames", type=int, default=32, help="frames of the CPU baseline sample")
     p.add_argument("--cpu-threads", type=int, default=0, help="0 = min(host cores, 64)")
     p.add_argument("--force-dist", action="store_true",
@@ -62,7 +74,7 @@ def parse():
     p.add_argument("--share-device0", action="store_true",
                    help="functional check of the N > 1 code path on a one-GPU box: every rank uses device 0 and the "
                         "all-gather runs over gloo (RCCL refuses two ranks on one device); not a measurement")
-    return p.parse_args()
+    return p.parse_args(argv)
 
 
 def make_batch(kind, rank, clips, seconds, distinct):
@@ -123,6 +135,7 @@ class DeviceSampler:
         import threading
         self.files, self.rows, self.stop_flag, self.period = None, [], False, period
         try:
+            import torch
             p = torch.cuda.get_device_properties(device_index)
             want = "%04x:%02x:%02x." % (p.pci_domain_id, p.pci_bus_id, p.pci_device_id)
             for dev in glob.glob("/sys/class/drm/card*/device"):
@@ -187,8 +200,42 @@ def rms_check(W, kind, eng, threads):
             "tolerance": 1e-3}
 
 
-def main():
-    a = parse()
+def launch_ranks(a, argv):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as child processes of this one
+    (which has not touched the GPU), one per GPU, rendezvous on 127.0.0.1, relay rank 0's JSON line,
+    and fail if any rank fails.  Under torch.distributed.run (WORLD_SIZE set) this is never reached."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(a.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(a.gpus), LOCAL_WORLD_SIZE=str(a.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out0 = procs[0].communicate()[0].decode()
+    codes = [p.wait() for p in procs]
+    sys.stdout.write(out0)
+    sys.stdout.flush()
+    bad = [(r, c) for r, c in enumerate(codes) if c != 0]
+    if bad:
+        sys.stderr.write("bench.py: rank(s) failed (rank, exit code): %s\n" % bad)
+        return 1
+    return 0
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else list(argv)
+    a = parse(argv)
+    if "WORLD_SIZE" not in os.environ:
+        if a.gpus > 1:
+            return launch_ranks(a, argv)
+    elif int(os.environ["WORLD_SIZE"]) != a.gpus and not a.force_dist:
+        sys.stderr.write("bench.py: --gpus %d but the launcher started WORLD_SIZE=%s ranks\n" % (a.gpus, os.environ["WORLD_SIZE"]))
+        return 2
+    _rank_imports()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -263,8 +310,20 @@ def main():
         prof = eng.profile()
         eng.set_option("profile", 0)
 
+    # what the f16 matrix pipes of THIS box sustain at its power cap, measured right after the workload while the
+    # socket is still warm: register-only v_mfma_f32_32x32x16_f16 on random operands (nhans_debug_mfma_ceiling)
+    ceiling = None
+    if rank == 0 and a.precision == "f16x3" and not a.no_ceiling:
+        from nhans_amd import hip as nh
+        cs = DeviceSampler(local, period=0.1)
+        cs.start()
+        ceiling = nh.mfma_ceiling(a.ceiling_seconds, eng._stream())
+        ceiling["device_state"] = cs.stop()
+        ceiling["seconds"] = a.ceiling_seconds
+
     if rank == 0:
         ms_step = 1e3 * dt / a.steps
+        cap_tf = ceiling["sustained_tflops"] if ceiling else (F16_MFMA_AT_POWER_CAP_TFLOPS if a.precision == "f16x3" else None)
         convs = {k: v for k, v in prof.items() if k.startswith("conv_igemm")}
         conv_ms = sum(v["ms"] for v in convs.values())
         conv_fl = sum(v["flops"] for v in convs.values())
@@ -319,9 +378,13 @@ def main():
                          # what back-to-back f16 MFMAs on random register operands sustain at the socket power cap
                          # (tools/ubench/mfma_power.hip, profiles/r02/mfma_power_ceiling.txt); the datasheet peak is
                          # reached with all-zero operands only
-                         "peak_at_power_cap": F16_MFMA_AT_POWER_CAP_TFLOPS if a.precision == "f16x3" else None,
-                         "executed_frac_of_peak_at_power_cap": tflops * 3 / F16_MFMA_AT_POWER_CAP_TFLOPS
-                         if a.precision == "f16x3" else None,
+                         "peak_at_power_cap": cap_tf,
+                         "executed_frac_of_peak_at_power_cap": tflops * 3 / cap_tf if cap_tf else None,
+                         "peak_at_power_cap_source": ("measured in this run on this device: %.1f s of back-to-back "
+                                                      "v_mfma_f32_32x32x16_f16 on random register operands after the timed "
+                                                      "region (nhans_debug_mfma_ceiling)" % a.ceiling_seconds) if ceiling
+                         else ("constant from profiles/r02/mfma_power_ceiling.txt (another box)" if cap_tf else None),
+                         "peak_at_power_cap_run": ceiling,
                          "source": "hipEvents around every launch in one extra pass after the timed region (%.1f ms wall)"
                                    % (kpass_ms or 0.0),
                          # the same algorithmic FLOPs over the UNPROFILED timed step (all kernels, launch gaps): lower bound
@@ -347,7 +410,8 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     eng.close()
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

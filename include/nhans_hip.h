@@ -79,8 +79,9 @@ int64_t nhans_num_frames(int64_t nsamples);
 int nhans_create(int model_kind, const void* folded_blob, size_t nbytes, int device_id, nhans_ctx** out);
 void nhans_destroy(nhans_ctx* ctx);
 
-/* Options: "frames_per_chunk" (mask-net frame windows per pass, default 3776: 20 GB of workspace for batches
- *           that large, chosen so that the launches fill whole waves of 256 workgroups),
+/* Options: "frames_per_chunk" (mask-net frame windows per pass, 1..4769 -- the conv kernels address a pass's
+ *           largest tensor, frames x 35 x 201 x 64 elements, with 32-bit offsets; default 3776: 20 GB of workspace
+ *           for batches that large, 5.4 MB per frame, chosen so that the launches fill whole waves of 256 workgroups),
  *          "contexts_per_chunk" (embedding-tower images per pass, default 64),
  *          "profile" (1: time every kernel launch with hipEvents on the launch stream),
  *          "precision" (0: exact f32 matrix-core path, default; 1: split-f16 x3 -- every operand is
@@ -95,6 +96,8 @@ void nhans_destroy(nhans_ctx* ctx);
  *          "consumer_interleave" (1, default: the MFMA waves of the halo kernel issue their LDS operand
  *           reads between their MFMAs, one behind each of the first MFMAs of a half-tap; 2: spread evenly over the
  *           half-tap; 0: read block then MFMA block -- identical bits, kept for A/B),
+ *          The next three select kernels that exist only in a `make AB=1` build (the default library refuses them
+ *          with NHANS_EINVAL; option "ab_build" returns NHANS_OK in such a build):
  *          "persistent_tiles" (0, default; 1: launches with >= 2 tiles per CU run the halo kernels as persistent
  *           workgroups whose DMA pipeline runs on across tile boundaries -- identical bits, measured 2-3 %
  *           slower, kept so that the measurement can be repeated),
@@ -165,6 +168,16 @@ int nhans_take_status(nhans_ctx* ctx, int* flags_out, void* stream);
  * NHANS_EHIP (with the runtime's message in nhans_last_error()) if not -- e.g. for a request above
  * the 160 KB a gfx950 CU has, or when no HIP device is present. */
 int nhans_debug_launch_probe(size_t dynamic_lds_bytes, void* stream);
+
+/* Measures what the f16 matrix pipes of the current device sustain at its socket power cap (needs no
+ * context): back-to-back independent v_mfma_f32_32x32x16_f16 -- the instruction the split-f16 conv kernels
+ * issue -- on pseudo-random register operands, no LDS, no memory, launch after launch for `seconds`
+ * (0 < seconds <= 60; blocks the calling thread).  *sustained_tflops = mean rate over the second half of the
+ * launches, *first_tflops (nullable) = the first launch (boost clock), *launches (nullable) = launches run.
+ * bench.py reports it as roofline.peak_at_power_cap: the data-sheet 2.5 PFLOP/s is reached only on operands
+ * that do not toggle the multipliers.  Replaces nothing in the reference: measurement. */
+int nhans_debug_mfma_ceiling(double seconds, void* stream, double* sustained_tflops, double* first_tflops,
+                             int* launches);
 
 /* Host helper (no device involved): CRC-32C (Castagnoli) of a host buffer continued from `crc`
  * (0 to start).  TensorFlow checkpoint bundles store crc32c::Mask() of it per tensor; tfbundle.py

@@ -78,8 +78,8 @@ def read_wav_any(in_path):
     converted" to 16 kHz / 16-bit PCM with sox; sox is not available, scipy does the same job):
     any PCM/float wav at any rate -> what read_wav() would have returned for the converted file."""
     rate, samples = wavread(in_path)
-    if rate == FLAGS.Fs and samples.dtype == np.int16:
-        return read_wav(in_path)
+    if rate == FLAGS.Fs and samples.dtype == np.int16:        # already what read_wav() accepts
+        return samples if samples.ndim == 1 else samples.mean(axis=1)
     x = samples.astype(np.float64)
     if samples.dtype == np.uint8:
         x = (x - 128.0) * 256.0
@@ -244,58 +244,88 @@ def write_separator_outputs(save_to, denoised_samples, mixed_samples):
     wavwrite(side_prefix(save_to) + 'mixed_processed.wav', FLAGS.Fs, mixed_samples)
 
 
+# Audio per nhans_enhance_clips call in directory mode: 4,096 s = 410 ten-second clips = 1.4 GB of
+# spectra and waveforms beside the fixed 20 GB stack workspace; a longer job list runs as several calls.
+MAX_CALL_SAMPLES = 4096 * Fs
+
+_owns_process_group = False
+
+
+def _enhance_in_calls(eng, mixes, ca, cb):
+    """-> [(denoised, mixed_processed)] per clip, the clips going through the hot path in as few
+    ragged calls as MAX_CALL_SAMPLES allows (one for any ordinary directory)."""
+    outs, i = [], 0
+    while i < len(mixes):
+        j, tot = i, 0
+        while j < len(mixes) and (j == i or tot + len(mixes[j]) <= MAX_CALL_SAMPLES):
+            tot += len(mixes[j])
+            j += 1
+        res = eng.enhance(mixes[i:j], ca[i:j], cb[i:j], want_mixed=True)
+        outs.extend(zip(res["denoised_wav"], res["mixed_wav"]))
+        i = j
+    return outs
+
+
 def apply_batch(kind, jobs):
     """Directory mode (README.md:59-66) as ONE batch: `jobs` is a list of (mixedpath, pospath,
-    negpath, save_to).  All recordings go through the hot path in a single ragged
-    `nhans_enhance_clips` call; under `python -m torch.distributed.run` (WORLD_SIZE > 1) the clips
-    are sharded over the ranks (clip i -> rank floor(i*G/N), dist.py), each rank runs its block on
-    its own GPU, one all-gather reassembles the waveforms and rank 0 writes the files.  Returns the
-    number of clips written by this rank."""
+    negpath, save_to).  The recordings go through the hot path in ragged `nhans_enhance_clips`
+    calls; under `python -m torch.distributed.run` (WORLD_SIZE > 1) the JOB LIST is sharded over the
+    ranks (job i -> rank floor(i*G/N), dist.py): each rank reads, converts and normalises only its
+    own block of files and runs it on its own GPU, one all-gather reassembles the waveforms (a job
+    whose files could not be read travels as a zero-length entry) and rank 0 writes the files.
+    Returns the number of clips written by this rank."""
     import torch
     from . import dist as nd
-    sigs, keep = [], []
-    for job in jobs:
-        mixedpath, pospath, negpath, _ = job
-        a_path, b_path = (pospath, negpath) if kind == spec.DENOISER else (negpath, pospath)
-        sig = handle_signals(mixedpath, a_path, b_path)
-        if sig is None:                     # unreadable triple: reported by handle_signals, skipped
-            continue
-        sigs.append(sig)
-        keep.append(job)
-    if not sigs:
-        return 0
-    ca = [s[0] for s in sigs]
-    cb = [s[1] for s in sigs]
-    mixes = [s[2] for s in sigs]
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
+    lo, hi = nd.shard_bounds(len(jobs), world, rank) if world > 1 else (0, len(jobs))
+    sigs = []
+    for mixedpath, pospath, negpath, _ in jobs[lo:hi]:
+        a_path, b_path = (pospath, negpath) if kind == spec.DENOISER else (negpath, pospath)
+        sigs.append(handle_signals(mixedpath, a_path, b_path))      # None: unreadable triple, reported there, skipped
+    good = [s for s in sigs if s is not None]
+    if world == 1 and not good:
+        return 0
     eng = get_engine(kind)
+    done = iter(_enhance_in_calls(eng, [s[2] for s in good], [s[0] for s in good], [s[1] for s in good]))
+    outs = [None if s is None else next(done) for s in sigs]
     if world > 1:
         import torch.distributed as tdist
         if not tdist.is_initialized():
+            global _owns_process_group
             tdist.init_process_group("nccl" if os.environ.get("NHANS_DIST_BACKEND", "nccl") == "nccl" else "gloo")
+            _owns_process_group = True
         gather_dev = eng.device if tdist.get_backend() == "nccl" else torch.device("cpu")
-
-        def run(m, a, b):
-            if not m:
-                return []
-            res = eng.enhance(m, a, b, want_mixed=True)
-            # denoised and round trip travel in one tensor per clip: ONE data all-gather (SURVEY 8e)
-            return [torch.from_numpy(np.concatenate([d, x])).to(gather_dev)
-                    for d, x in zip(res["denoised_wav"], res["mixed_wav"])]
-        both = nd.enhance_sharded(run, mixes, ca, cb, gather_dev)
+        # denoised and round trip travel in one tensor per clip: ONE data all-gather (SURVEY 8e)
+        local = [torch.zeros(0) if o is None else torch.from_numpy(np.concatenate(o)) for o in outs]
+        both = nd.gather_ragged([t.to(gather_dev) for t in local], len(jobs), gather_dev)
         if rank != 0:
             return 0
-        outs = [(t[:t.numel() // 2].cpu().numpy(), t[t.numel() // 2:].cpu().numpy()) for t in both]
-    else:
-        res = eng.enhance(mixes, ca, cb, want_mixed=True)
-        outs = list(zip(res["denoised_wav"], res["mixed_wav"]))
-    for (_, _, _, save_to), (den, mixed) in zip(keep, outs):
+        outs = [None if t.numel() == 0 else (t[:t.numel() // 2].cpu().numpy(), t[t.numel() // 2:].cpu().numpy())
+                for t in both]
+    written = 0
+    for (_, _, _, save_to), o in zip(jobs, outs):
+        if o is None:
+            continue
         if kind == spec.DENOISER:
-            write_snc_outputs(save_to, den, mixed)
+            write_snc_outputs(save_to, o[0], o[1])
         else:
-            write_separator_outputs(save_to, den, mixed)
-    return len(outs)
+            write_separator_outputs(save_to, o[0], o[1])
+        written += 1
+    return written
+
+
+def finish_distributed():
+    """End of a sharded CLI run: the other ranks wait until rank 0 has written the files, then the
+    process group this module created is torn down (no RCCL teardown warnings from early exits)."""
+    global _owns_process_group
+    if not _owns_process_group:
+        return
+    import torch.distributed as tdist
+    if tdist.is_initialized():
+        tdist.barrier()
+        tdist.destroy_process_group()
+    _owns_process_group = False
 
 
 # ------------------------------------------------------------------------------ demo / eval mode
@@ -420,7 +450,10 @@ def _run_cli(kind, a):
     jobs = list(_pairs(a))
     if os.path.isdir(a.input) or int(os.environ.get("WORLD_SIZE", "1")) > 1:
         _bind_rank_device()
-        apply_batch(kind, jobs)
+        try:
+            apply_batch(kind, jobs)
+        finally:
+            finish_distributed()
     else:
         for mixed, pos, neg, out in jobs:
             (apply_snc if kind == spec.DENOISER else apply_separator)(mixed, pos, neg, out)

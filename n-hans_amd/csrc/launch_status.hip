@@ -13,7 +13,8 @@ thread_local hipError_t g_first_err = hipSuccess;
 thread_local const char* g_first_where = "";
 
 void keep(hipError_t e, const char* where) {
-    if (e != hipSuccess && g_first_err == hipSuccess) {
+    // (hipErrorNotReady is what an event/stream QUERY of the application leaves behind: not a failure)
+    if (e != hipSuccess && e != hipErrorNotReady && g_first_err == hipSuccess) {
         g_first_err = e;
         g_first_where = where;
     }

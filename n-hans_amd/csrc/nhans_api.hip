@@ -565,6 +565,15 @@ struct Call {
     Call(nhans_ctx* c_, void* stream) : c(c_), s(static_cast<hipStream_t>(stream)), rc(check_ctx(c_)) {
         if (rc) return;
         (void)take_launch_error(nullptr);               // (a stale record of another context's failure)
+        // note_launch() reads the runtime's sticky per-thread error, which an earlier HIP call of the
+        // APPLICATION may have left set: it must neither be blamed on this library's first kernel nor be
+        // consumed on the application's behalf -- peek, do not clear, and refuse to run on top of it.
+        const hipError_t pending = hipPeekAtLastError();
+        if (pending != hipSuccess && pending != hipErrorNotReady) {
+            rc = fail(NHANS_EHIP, std::string("a HIP error was already pending on the calling thread before this call "
+                                              "(left by the application, not cleared): ") + hipGetErrorString(pending));
+            return;
+        }
         if (c->have_tail && c->last_stream != s) {
             const hipError_t e = hipStreamWaitEvent(s, c->tail_ev, 0);
             if (e != hipSuccess) rc = fail(NHANS_EHIP, std::string("hipStreamWaitEvent: ") + hipGetErrorString(e));
@@ -698,7 +707,14 @@ void nhans_destroy(nhans_ctx* c) {
 int nhans_set_option(nhans_ctx* c, const char* key, int64_t value) {
     if (!c || !key) return fail(NHANS_EINVAL, "null argument");
     const std::string k(key);
-    if (k == "frames_per_chunk") { if (value < 1) return fail(NHANS_EINVAL, "frames_per_chunk < 1"); c->frames_per_chunk = value; }
+    if (k == "frames_per_chunk") {
+        // the fast conv kernels address a tensor with 32-bit element offsets: the largest one of a pass
+        // (frames x 35 x 201 x 64) must stay below 2^31 elements, i.e. at most 4,769 frames; above that every
+        // layer would silently fall back to the slow kernel, far above it M = frames x Ho x Wo overflows int
+        if (value < 1 || value > kMaxFramesPerChunk)
+            return fail(NHANS_EINVAL, "frames_per_chunk must be in [1, " + std::to_string(kMaxFramesPerChunk) + "]");
+        c->frames_per_chunk = value;
+    }
     else if (k == "contexts_per_chunk") { if (value < 1) return fail(NHANS_EINVAL, "contexts_per_chunk < 1"); c->contexts_per_chunk = (int)value; }
     else if (k == "profile") c->profile = value != 0;
     else if (k == "debug_cycles_ptr") {
@@ -710,12 +726,16 @@ int nhans_set_option(nhans_ctx* c, const char* key, int64_t value) {
         if (value < 0 || value > 2) return fail(NHANS_EINVAL, "consumer_interleave must be 0, 1 or 2");
         c->ilv = (int)value;
     }
-    else if (k == "persistent_tiles") c->persist = value != 0;
-    else if (k == "quad_workgroups") c->quad = value != 0;
+    else if (k == "persistent_tiles" || k == "quad_workgroups") {
+        if (!kAB && value != 0) return fail(NHANS_EINVAL, k + " exists only in a `make AB=1` build of the library");
+        (k == "persistent_tiles" ? c->persist : c->quad) = value != 0;
+    }
     else if (k == "conv_variant") {
         if (value < -1 || value > 3) return fail(NHANS_EINVAL, "conv_variant must be -1 (auto), 0, 1, 2 or 3");
+        if (!kAB && value == 3) return fail(NHANS_EINVAL, "conv_variant 3 exists only in a `make AB=1` build of the library");
         c->conv_variant = (int)value;
     }
+    else if (k == "ab_build") return kAB ? NHANS_OK : fail(NHANS_EINVAL, "not an AB=1 build");   // query: 0 = yes
     else if (k == "precision") {
         if (value != 0 && value != 1) return fail(NHANS_EINVAL, "precision must be 0 (f32) or 1 (f16x3)");
         if (value == 1 && !c->A("head.dense.wpk_h"))
@@ -919,10 +939,14 @@ int nhans_take_status(nhans_ctx* c, int* flags_out, void* stream) {
     int rc = check_ctx(c); if (rc) return rc;
     if (!flags_out) return fail(NHANS_EINVAL, "null argument");
     hipStream_t s = static_cast<hipStream_t>(stream);
+    // the kernels that set the bits may have run on another stream than the one given here: order the
+    // read-and-clear behind the context's last call, as every hot-path entry point does (struct Call)
+    if (c->have_tail && c->last_stream != s) HIP_TRY(hipStreamWaitEvent(s, c->tail_ev, 0));
     int flags = 0;
     HIP_TRY(hipMemcpyAsync(&flags, c->status_dev, sizeof(int), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipMemsetAsync(c->status_dev, 0, sizeof(int), s));
     HIP_TRY(hipStreamSynchronize(s));
+    if (hipEventRecord(c->tail_ev, s) == hipSuccess) { c->have_tail = true; c->last_stream = s; }   // the clear is part of the order
     *flags_out = flags;
     return NHANS_OK;
 }

@@ -7,6 +7,8 @@ namespace nhans {
 
 constexpr int kWin = 400, kHop = 160, kBins = 201, kMixWin = 35, kCtxFrames = 200, kEmb = 512;
 constexpr int kCenter = kMixWin / 2;
+// frame windows per pass of the stack: frames x 35 x 201 x 64 elements < 2^31 (32-bit element offsets in the conv kernels)
+constexpr int64_t kMaxFramesPerChunk = ((int64_t)1 << 31) / ((int64_t)kMixWin * kBins * 64);
 
 // Developer tooling (cycle stamps, timing ablations that compute WRONG results, kernel-choice
 // switches read from the environment) exists only in a `make DEV=1` build (-DNHANS_DEV); the
@@ -19,6 +21,17 @@ bool dev_halo2d_enabled(); // getenv("NHANS_HALO2D") != "0"
 constexpr bool kDev = false;
 constexpr int dev_ablate() { return 0; }
 constexpr bool dev_halo2d_enabled() { return true; }
+#endif
+
+// The A/B conv kernels that every measurement of rounds 1-2 found no faster than the default ones
+// (persistent workgroups: conv_igemm_halop.hip; four-wave workgroups, two per CU: conv_igemm_quad.hip;
+// 2-D 256-pixel tiles for the 64-channel convs: conv_igemm_halo2d.hip) are compiled only into a
+// `make AB=1` build (-DNHANS_AB), where the options persistent_tiles / quad_workgroups /
+// conv_variant 3 select them; the default library is built without them and refuses those options.
+#ifdef NHANS_AB
+constexpr bool kAB = true;
+#else
+constexpr bool kAB = false;
 #endif
 
 // ---------------------------------------------------------------------------------------------
@@ -135,10 +148,17 @@ double launch_conv_igemm(const ConvArgs& a, hipStream_t s, const char** kernel =
 void launch_conv_igemm_dma(const ConvArgs& a, hipStream_t s);   // conv_igemm_dma.hip
 bool conv_igemm_halo_eligible(const ConvArgs& a);               // conv_igemm_halo.hip
 void launch_conv_igemm_halo(const ConvArgs& a, hipStream_t s);
+#ifdef NHANS_AB
 bool conv_igemm_quad_eligible(const ConvArgs& a);                         // conv_igemm_quad.hip
 void launch_conv_igemm_quad(const ConvArgs& a, hipStream_t s);
 bool launch_conv_igemm_halo_persist(const ConvArgs& a, hipStream_t s);   // conv_igemm_halop.hip; false = not applicable, nothing launched
 bool launch_conv_igemm_halo2d(const ConvArgs& a, hipStream_t s);  // conv_igemm_halo2d.hip; false = not eligible, nothing launched
+#else
+inline bool conv_igemm_quad_eligible(const ConvArgs&) { return false; }
+inline void launch_conv_igemm_quad(const ConvArgs&, hipStream_t) {}
+inline bool launch_conv_igemm_halo_persist(const ConvArgs&, hipStream_t) { return false; }
+inline bool launch_conv_igemm_halo2d(const ConvArgs&, hipStream_t) { return false; }
+#endif
 
 // ---------------------------------------------------------------------------------------------
 // Small kernels (aux_kernels.hip)

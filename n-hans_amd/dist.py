@@ -3,7 +3,8 @@
 Clips are independent, so the batch is cut into contiguous blocks, one per rank (weights are
 replicated), each rank runs the whole hot path on its block, and ONE all-gather over RCCL/xGMI
 reassembles the output waveforms on every rank.  Ragged lengths: the int64 lengths are gathered
-first and the waveforms are padded to the longest clip for the gather.
+first; each rank then contributes its clips back to back in one flat buffer (padded to the largest
+per-rank total only).
 
 `backend` is whatever the process group was initialised with: "nccl" (= RCCL) on GPUs, "gloo" on
 CPU (tests/test_dist_cpu.py runs world_size 2 with a stand-in enhance function).
@@ -25,26 +26,39 @@ def shard(items, world, rank):
 
 
 def gather_ragged(local, n_total, device, group=None):
-    """local: list of 1-D float32 tensors (this rank's outputs, in order).  Returns the list of all
-    n_total outputs in global order on every rank.  Two collectives: lengths, then padded data."""
+    """local: list of 1-D float32 tensors (this rank's outputs, in order; a zero-length tensor stands
+    for a clip that produced nothing).  Returns the list of all n_total outputs in global order on
+    every rank.  Two collectives: the lengths, then ONE all-gather of data.
+
+    Each rank sends its clips back to back in one flat buffer, padded only to the largest per-rank
+    TOTAL -- not every clip to the longest clip of the job: one ten-minute recording among thousands
+    of short ones costs its own length once, not once per clip.  The lengths come to the host in one
+    copy (no per-clip device read)."""
     world = dist.get_world_size(group)
-    per = max(shard_bounds(n_total, world, r)[1] - shard_bounds(n_total, world, r)[0] for r in range(world))
-    lens = torch.zeros(per, dtype=torch.int64, device=device)
+    bounds = [shard_bounds(n_total, world, r) for r in range(world)]
+    per = max(hi - lo for lo, hi in bounds) if bounds else 0
+    lens = torch.zeros(max(per, 1), dtype=torch.int64)
     for i, t in enumerate(local):
         lens[i] = t.numel()
-    all_lens = torch.empty(world * per, dtype=torch.int64, device=device)
+    lens = lens.to(device)
+    all_lens = torch.empty(world * max(per, 1), dtype=torch.int64, device=device)
     dist.all_gather_into_tensor(all_lens, lens, group=group)
-    maxlen = int(all_lens.max().item()) if all_lens.numel() else 0
-    buf = torch.zeros((per, maxlen), dtype=torch.float32, device=device)
-    for i, t in enumerate(local):
-        buf[i, :t.numel()] = t
-    out = torch.empty((world * per, maxlen), dtype=torch.float32, device=device)
-    dist.all_gather_into_tensor(out, buf, group=group)
+    all_lens = all_lens.cpu().view(world, max(per, 1))          # the one device -> host read
+    rank_total = all_lens.sum(dim=1)
+    width = int(rank_total.max()) if n_total else 0
+    flat = torch.zeros(max(width, 1), dtype=torch.float32, device=device)
+    if local:
+        torch.cat([t.reshape(-1) for t in local], out=flat[:sum(t.numel() for t in local)])
+    out = torch.empty(world * max(width, 1), dtype=torch.float32, device=device)
+    dist.all_gather_into_tensor(out, flat, group=group)
+    out = out.view(world, max(width, 1))
     res = []
-    for r in range(world):
-        lo, hi = shard_bounds(n_total, world, r)
+    for r, (lo, hi) in enumerate(bounds):
+        at = 0
         for j in range(hi - lo):
-            res.append(out[r * per + j, :int(all_lens[r * per + j].item())])
+            n = int(all_lens[r, j])
+            res.append(out[r, at:at + n])
+            at += n
     return res
 
 

@@ -17,6 +17,7 @@ EXPORTS = [
     "nhans_set_option", "nhans_workspace_bytes", "nhans_stft_features", "nhans_embed",
     "nhans_mask_net", "nhans_istft", "nhans_enhance_clips", "nhans_debug_block_output",
     "nhans_profile_json", "nhans_profile_reset", "nhans_take_status", "nhans_debug_launch_probe", "nhans_crc32c",
+    "nhans_debug_mfma_ceiling",
 ]
 STATUS_SATURATED = 1
 
@@ -59,6 +60,9 @@ def load():
     lib.nhans_profile_reset.argtypes = [vp]
     lib.nhans_take_status.argtypes = [vp, ctypes.POINTER(ctypes.c_int), vp]
     lib.nhans_debug_launch_probe.argtypes = [ctypes.c_size_t, vp]
+    lib.nhans_debug_mfma_ceiling.argtypes = [ctypes.c_double, vp, ctypes.POINTER(ctypes.c_double),
+                                             ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int)]
+    lib.nhans_debug_mfma_ceiling.restype = ctypes.c_int
     lib.nhans_crc32c.argtypes = [ctypes.c_uint32, vp, ctypes.c_size_t]
     lib.nhans_crc32c.restype = ctypes.c_uint32
     for name in ("nhans_create", "nhans_set_option", "nhans_stft_features", "nhans_embed", "nhans_mask_net",
@@ -88,6 +92,19 @@ def ptr(t):
         return None
     assert t.is_contiguous()
     return ctypes.c_void_p(t.data_ptr())
+
+
+def mfma_ceiling(seconds, stream=None):
+    """-> dict(sustained_tflops, first_launch_tflops, launches): the f16 MFMA rate the current device
+    holds at its power cap (nhans_debug_mfma_ceiling)."""
+    sus, first, n = ctypes.c_double(0), ctypes.c_double(0), ctypes.c_int(0)
+    check(load().nhans_debug_mfma_ceiling(float(seconds), stream, ctypes.byref(sus), ctypes.byref(first), ctypes.byref(n)))
+    return {"sustained_tflops": sus.value, "first_launch_tflops": first.value, "launches": n.value}
+
+
+def ab_build(handle):
+    """True when the library was built with `make AB=1` (the A/B conv kernels are present)."""
+    return load().nhans_set_option(handle, b"ab_build", 0) == 0
 
 
 def profile_dict(handle):

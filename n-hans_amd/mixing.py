@@ -3,7 +3,11 @@
 the separator (SS/apply.py:54-108).  Restated with the reference's arithmetic, including its
 quirks, so that the device path is fed bit-identical waveforms:
 
-  * powers are accumulated with Python's builtin sum() over float32 samples (sequential float32);
+  * powers: `sum(abs(x) * abs(x)) / n` with Python's builtin sum().  The reference is pinned to
+    TensorFlow 1.14 / NumPy 1.x, where `0 + np.float32` is a float64 (value-based promotion of the
+    int start value), so the float32 squares are added one after the other IN FLOAT64 and the gain
+    is a float64 scalar; a float64 scalar times a float32 array stays float32 there (the scalar is
+    cast down).  NumPy 2 (this image) would do both differently, so both are spelled out here;
   * after `mixed` has been normalised, the *already normalised* mixed is used again to "normalise"
     target and the two noise signals (SN/apply.py:98-102), i.e. they are divided by ~1, not by the
     mixture's original peak;
@@ -32,13 +36,21 @@ def _fit_length(noise, n):
 
 
 def _mean_power(x):
-    """Mean square of a float32 recording, accumulated the way the reference does it: one sample
-    after the other in float32 (its builtin sum() over numpy scalars; np.add.accumulate on a 1-D
-    float32 array performs the same left-to-right additions, without the per-element Python cost)."""
+    """Mean square of a recording the way the reference's stack computes it: squares in the
+    recording's own precision, then added one after the other in float64 (builtin sum() under
+    NumPy 1.x, see the module text; np.add.accumulate performs the same left-to-right additions
+    without the per-element Python cost)."""
     sq = np.abs(x) * np.abs(x)
-    if sq.dtype != np.float32 or sq.ndim != 1 or len(sq) == 0:
+    if sq.ndim != 1 or len(sq) == 0:
         return sum(sq) / x.shape[0]
-    return np.add.accumulate(sq)[-1] / x.shape[0]
+    return np.add.accumulate(sq.astype(np.float64))[-1] / x.shape[0]
+
+
+def _scaled(gain, x):
+    """gain * x with NumPy 1.x casting: a float scalar never widens a floating-point array."""
+    if isinstance(x, np.ndarray) and x.dtype.kind == 'f':
+        return x.dtype.type(gain) * x
+    return gain * x
 
 
 def _gain_for_snr(p_speech, p_noise, snr_db):
@@ -66,8 +78,8 @@ def domixing(speech, noise_keep, noise_drop, snr_keep_db, snr_drop_db):
     p_speech = _mean_power(speech)
     gain_keep = _gain_for_snr(p_speech, _mean_power(keep), snr_keep_db)
     gain_drop = _gain_for_snr(p_speech, _mean_power(drop), snr_drop_db)
-    keep_scaled = gain_keep * keep
-    drop_scaled = gain_drop * drop
+    keep_scaled = _scaled(gain_keep, keep)
+    drop_scaled = _scaled(gain_drop, drop)
     raw = speech + keep_scaled + drop_scaled
     mixture = raw / _peak(raw)
     unit = _peak(mixture)
@@ -79,7 +91,7 @@ def domixing_separator(target_speech, interferer, snr_db):
     (mixture, gain) with the mixture peak-normalised."""
     other = _fit_length(interferer, len(target_speech))
     gain = _gain_for_snr(_mean_power(target_speech), _mean_power(other), snr_db)
-    raw = target_speech + gain * other
+    raw = target_speech + _scaled(gain, other)
     return raw / _peak(raw), gain
 
 
@@ -117,4 +129,4 @@ def combine_signals_separator(read_wav, cleanpath, noisepath):
     clean = clean[:-((len(clean) - spec.WIN) % spec.HOP)]     # sic: unconditional (see module doc)
     snr = 0
     mixed, K = domixing_separator(clean, noise, snr)
-    return clean, noise * K, mixed, np.array(snr, dtype=np.int32)
+    return clean, _scaled(K, noise), mixed, np.array(snr, dtype=np.int32)

@@ -316,15 +316,25 @@ def _fit(noise, n):
     return noise[:n] if n - len(noise) < 0 else nse
 
 
+def power(x):
+    """`sum(abs(x) * abs(x)) / x.shape[0]` (SN/apply.py:75-77) as the reference's pinned stack
+    (TF 1.14, NumPy 1.x) evaluates it: builtin sum() starts from the int 0, `0 + np.float32` is a
+    float64 there, so the float32 squares are accumulated sequentially in float64."""
+    acc = 0.0
+    for v in (abs(x) * abs(x)).tolist():
+        acc += v
+    return np.float64(acc) / x.shape[0]
+
+
 def domixing(clean, pos, neg, snr_pos, snr_neg):
     """SN/apply.py:56-104 (== SN/reader.py:128-176), including the re-use of the normalised `mixed`
     when "normalising" target and the noise signals (:98-102)."""
     nse_pos, nse_neg = _fit(pos, len(clean)), _fit(neg, len(clean))
-    power = lambda x: sum(abs(x) * abs(x)) / x.shape[0]
     ps, pp, pn = power(clean), power(nse_pos), power(nse_neg)
     k_pos = 1 if pp == 0 else np.sqrt((ps / pp) * pow(10, -snr_pos / 10.0))
     k_neg = 1 if pn == 0 else np.sqrt((ps / pn) * pow(10, -snr_neg / 10.0))
-    pos_s, neg_s = k_pos * nse_pos, k_neg * nse_neg
+    # (NumPy 1.x: a float64 scalar times a float32 array is a float32 product)
+    pos_s, neg_s = nse_pos.dtype.type(k_pos) * nse_pos, nse_neg.dtype.type(k_neg) * nse_neg
     mixed = clean + pos_s + neg_s
     mixed = mixed / (max(abs(mixed)) + 0.000001)
     peak = max(abs(mixed)) + 0.000001

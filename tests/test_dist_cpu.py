@@ -47,6 +47,24 @@ def _worker(rank, world, port, q):
     # a batch smaller than the world: rank 1 owns nothing
     out1 = nd.enhance_sharded(_fake_enhance, mixes[:1], ca[:1], cb[:1], torch.device("cpu"))
     ok = ok and len(out1) == 1 and torch.equal(out1[0], ref[0])
+    # one long recording among short ones: the data all-gather carries each rank's clips back to back, padded to the
+    # largest per-rank TOTAL (not every clip to the longest clip), and a zero-length entry (skipped job) survives
+    lens2 = [400, 100000, 0, 400, 560, 400]
+    loc = [torch.full((n,), float(i + 1)) for i, n in enumerate(lens2)]
+    lo, hi = nd.shard_bounds(len(lens2), world, rank)
+    sizes = []
+    real = dist.all_gather_into_tensor
+
+    def spy(out, inp, group=None):
+        sizes.append(out.numel())
+        return real(out, inp, group=group)
+    nd.dist.all_gather_into_tensor = spy
+    try:
+        got = nd.gather_ragged(loc[lo:hi], len(lens2), torch.device("cpu"))
+    finally:
+        nd.dist.all_gather_into_tensor = real
+    ok = ok and [t.numel() for t in got] == lens2 and all(torch.equal(a, b) for a, b in zip(got, loc))
+    ok = ok and sizes == [world * 3, world * (400 + 100000 + 0)]            # lengths, then data: 2 x 100,400, not 6 x 100,000
     q.put((rank, ok))
     dist.destroy_process_group()
 
@@ -86,15 +104,20 @@ def _cli_worker(rank, world, port, argv, q):
     from nhans_amd import apply
     fake = _FakeEngine()
     apply.set_engine("denoiser", fake)
+    opened, real = [], apply.wavread
+
+    def spy(path, *a, **k):
+        opened.append(os.path.basename(os.path.dirname(path)) + "/" + os.path.basename(path))
+        return real(path, *a, **k)
+    apply.wavread = spy
     apply.main(argv)
-    dist.barrier()
-    dist.destroy_process_group()
-    q.put((rank, fake.calls))
+    q.put((rank, fake.calls, dist.is_initialized(), sorted(n for n in opened if n.startswith("in/"))))
 
 
 def test_cli_directory_mode_shards_clips_over_two_ranks(tmp_path):
-    """`nhans_denoiser --input <dir>` under WORLD_SIZE=2: 5 clips -> blocks of 3 and 2, ONE engine call per rank,
-    one all-gather, rank 0 writes every file -- identical to what a single rank writes."""
+    """`nhans_denoiser --input <dir>` under WORLD_SIZE=2: 6 jobs -> blocks of 3 and 3, every rank READS only its own
+    block (one of rank 0's files is unreadable), ONE engine call per rank, one all-gather, rank 0 writes every
+    file -- identical to what a single rank writes."""
     from scipy.io import wavfile
     from nhans_amd import apply, synth
     ind, negd = tmp_path / "in", tmp_path / "neg"
@@ -104,6 +127,8 @@ def test_cli_directory_mode_shards_clips_over_two_ranks(tmp_path):
     for i, n in enumerate(names):
         wavfile.write(str(ind / n), 16000, synth.mixture(70 + i, 0.05 + 0.03 * i))
         wavfile.write(str(negd / n), 16000, synth.noise_context(70 + i, 1.0))
+    (ind / "bad.wav").write_bytes(b"this is not a wav file")          # job 0 of rank 0: reported, skipped, nothing written
+    wavfile.write(str(negd / "bad.wav"), 16000, synth.noise_context(1, 1.0))
     common = ["--input", str(ind), "--neg", str(negd), "--pos", str(tmp_path / "Silent.wav"), "--weights", "synthetic"]
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -117,7 +142,7 @@ def test_cli_directory_mode_shards_clips_over_two_ranks(tmp_path):
     res = sorted(q.get(timeout=180) for _ in procs)
     for p in procs:
         p.join(timeout=60)
-    assert res == [(0, [3]), (1, [2])]                       # contiguous blocks, one batched call per rank
+    assert res == [(0, [2], False, ['in/bad.wav', 'in/c0.wav', 'in/c1.wav']), (1, [3], False, ['in/c2.wav', 'in/c3.wav', 'in/c4.wav'])]         # contiguous blocks, one batched call per rank; the CLI tore its process group down
     fake = _FakeEngine()
     apply.set_engine("denoiser", fake)
     try:

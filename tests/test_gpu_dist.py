@@ -145,9 +145,7 @@ def _cli_rank(rank, world, port, argv, q):
         from nhans_amd import apply
         apply.main(argv)
         import torch.distributed as tdist
-        tdist.barrier()
-        tdist.destroy_process_group()
-        q.put((rank, True, ""))
+        q.put((rank, not tdist.is_initialized(), ""))       # the CLI waits for rank 0's writes and tears its group down
     except Exception as e:
         import traceback
         q.put((rank, False, traceback.format_exc() + repr(e)))
@@ -209,3 +207,47 @@ def _cli_single(argv, q):
     except Exception as e:
         import traceback
         q.put(traceback.format_exc() + repr(e))
+
+
+def _bench_launcher(argv, q):
+    """`python bench.py <argv>` as the driver would start it, from a process that has not touched the GPU."""
+    try:
+        import contextlib
+        import io
+        import sys
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        sys.path.insert(0, root)
+        for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+            os.environ.pop(k, None)
+        import bench
+        buf = io.StringIO()
+        with contextlib.redirect_stdout(buf):
+            rc = bench.main(argv)
+        q.put((rc, buf.getvalue()))
+    except BaseException as e:
+        import traceback
+        q.put((-1, traceback.format_exc() + repr(e)))
+
+
+def test_bench_gpus_n_without_a_launcher_starts_n_ranks(lib_built):
+    """`python bench.py --gpus 2 ...` with no torch.distributed.run around it (the shape the driver uses): the
+    parent starts two rank processes itself, rank 0's JSON line says n_gpus 2 and counts both ranks' clips;
+    a mismatch between --gpus and a launcher's WORLD_SIZE is an error, not a silently different run.  (Both
+    ranks share device 0 over gloo here: the driver's box has one GPU.)"""
+    import json
+    ctx = mp.get_context("forkserver")
+    q = ctx.Queue()
+    argv = ["--gpus", "2", "--share-device0", "--clips-per-gpu", "4", "--seconds", "1", "--steps", "2", "--warmup", "1",
+            "--no-kernel-pass", "--no-cpu-baseline"]
+    p = ctx.Process(target=_bench_launcher, args=(argv, q))
+    p.start()
+    rc, out = q.get(timeout=900)
+    p.join(timeout=60)
+    assert rc == 0, out
+    lines = [ln for ln in out.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["config"]["clips_per_gpu"] == 4 and line["steps"] == 2
+    assert line["frames_per_s"] > 0 and line["status_flags"] == 0
+    audio_per_step = 2 * 4 * (98 * 160 + 240) / 16000.0                  # both ranks' clips, trimmed to 98 frames
+    assert abs(line["value"] * line["ms_per_step"] * 1e-3 - audio_per_step) < 1e-6 * audio_per_step

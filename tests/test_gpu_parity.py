@@ -141,12 +141,24 @@ def test_ten_second_clip_selected_frames(eng_d):
     assert np.abs(lg.cpu().numpy()[fr] - g["logits"]).max() < LOGIT_TOL
 
 
+def _needs_ab(eng, option, value):
+    """persistent_tiles / quad_workgroups / conv_variant 3 select kernels that only a `make AB=1` build of
+    the library contains (include/nhans_hip.h); the default build must REFUSE them, which is checked here."""
+    from nhans_amd import hip
+    if (option in ("persistent_tiles", "quad_workgroups") and value) or (option == "conv_variant" and value == 3):
+        if not hip.ab_build(eng.handle):
+            with pytest.raises(hip.NhansError, match="AB=1"):
+                eng.set_option(option, value)
+            pytest.skip("A/B kernel not in the default build (make AB=1)")
+
+
 @pytest.mark.parametrize("variant", [0, 1, 2, 3])
 @pytest.mark.parametrize("prec", ["f32", "f16x3"])
 def test_every_conv_kernel_variant(_eng_d, prec, variant):
     """The three conv kernels (register-staged, LDS-DMA, halo + producer/consumer waves) in both
     arithmetic modes against the same golden logits: 308-frame clip, and 998 frames so that tiles
     span many frame-windows and the ragged last tile of every layer is exercised."""
+    _needs_ab(_eng_d, "conv_variant", variant)
     _eng_d.set_precision(prec)
     _eng_d.set_option("conv_variant", variant)
     try:
@@ -185,6 +197,7 @@ def test_speed_knobs_do_not_change_a_bit(_eng_d, option, values):
     a 10 s clip (thousands of tiles per layer, so that the persistent kernels really run) must give
     identical logits whichever way they are set.  (conv_variant 3 = 2-D tiles for the 64-channel convs sums in
     another order: within tolerance, not bitwise.)"""
+    _needs_ab(_eng_d, option, values[0])
     _eng_d.set_precision("f16x3")
     g = load_case("case_synth10s")
     lm = torch.from_numpy(g["logmag"]).cuda()
@@ -208,6 +221,7 @@ def test_clip_boundary_inside_the_partial_last_tile(_eng_d, quad):
     and the one-frame clip after it.  The epilogue decides "one clip per tile -> load the conditioning bias once"
     from the first and last row of the tile; rows past the end used to look like the first row, so the last clip's
     frame got its neighbour's bias (logits off by up to 7e-2).  Every clip must equal the same clip run alone."""
+    _needs_ab(_eng_d, "quad_workgroups", quad)
     _eng_d.set_precision("f16x3")
     secs = (0.1, 0.025, 0.33, 0.025)                        # 8 + 1 + 31 + 1 frames; different conditioning per clip
     mixes = [apply.trim_to_frames(apply.normalise(synth.mixture(70 + i, d))) for i, d in enumerate(secs)]
@@ -233,6 +247,7 @@ def test_clip_boundary_inside_the_partial_last_tile(_eng_d, quad):
 def test_quad_workgroups_whole_path_bitwise(_eng_d):
     """Option quad_workgroups (conv_igemm_quad.hip: four-wave workgroups, two per CU, for the N >= 128 stride-1
     convs of the tower and the stack) must not change a bit of anything: ragged 3-clip batch incl. a one-frame clip."""
+    _needs_ab(_eng_d, "quad_workgroups", 1)
     _eng_d.set_precision("f16x3")
     mixes = [apply.trim_to_frames(apply.normalise(synth.mixture(40 + i, d))) for i, d in enumerate((0.025, 1.3, 0.6))]
     ca = [apply.normalise(synth.noise_context(40 + i)) for i in range(3)]

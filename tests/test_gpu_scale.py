@@ -119,29 +119,83 @@ def test_batch_of_256_ten_second_clips(eng):
         assert float((rt[i][240:-240] - x[240:-240]).abs().max()) < 2e-4
 
 
-def test_chunk_beyond_the_32bit_offset_limit_of_the_halo_kernels(eng):
-    """frames_per_chunk is a free option: 6,000 frame windows make the 64-channel tensors 2.7e9 elements, past the
-    32-bit element offsets of the halo kernels -- those layers must fall back to the 64-bit-offset LDS-DMA kernel
-    (checked through the profile) and the result must agree with the default chunking to rounding, finite, unsaturated."""
+def test_largest_chunk_the_fast_kernels_address(eng):
+    """frames_per_chunk is bounded by the conv kernels' 32-bit element offsets: 4,769 frame windows (the largest
+    tensor is then 2,147,194,560 elements) is accepted and runs every layer on the SAME kernels as the default
+    chunking (checked through the profile: no launch falls back to the 64-bit-offset LDS-DMA kernel), bit-identical
+    to it; one more is refused with NHANS_EINVAL instead of silently running slow (or overflowing int at 305,000)."""
     eng.set_precision("f16x3")
-    clips = [_clip(900 + i, 10.0) for i in range(6)]                     # 5,988 frames: one chunk of 6,000
+    clips = [_clip(900 + i, 10.0) for i in range(5)]                     # 4,990 frames: chunks of 4,769 + 221
     args = ([c[0] for c in clips], [c[1] for c in clips], [c[2] for c in clips])
-    ref = eng.enhance(*args, want_mixed=False, taps=True)
-    try:
-        eng.set_option("frames_per_chunk", 6000)
+
+    def run():
         eng.set_option("profile", 1)
         eng.profile_reset()
-        got = eng.enhance(*args, want_mixed=False, taps=True)
+        out = eng.enhance(*args, want_mixed=False, taps=True)
         calls = {k: v["calls"] for k, v in eng.profile().items() if k.startswith("conv_igemm")}
+        eng.set_option("profile", 0)
+        return out, calls
+    ref, ref_calls = run()
+    try:
+        with pytest.raises(hip.NhansError, match="frames_per_chunk"):
+            eng.set_option("frames_per_chunk", 4770)
+        with pytest.raises(hip.NhansError, match="frames_per_chunk"):
+            eng.set_option("frames_per_chunk", 400000)
+        eng.set_option("frames_per_chunk", 4769)
+        got, calls = run()
     finally:
         eng.set_option("profile", 0)
         eng.set_option("frames_per_chunk", 3776)
-    # the three 64-channel convs of the one stack chunk on the fallback kernel; the halo<64,512> launch left is the tower's
-    assert calls.get("conv_igemm_dma<64>") == 3 and calls.get("conv_igemm_halo<64,512>") == 1, calls
-    assert np.isfinite(got["logits"]).all() and eng.take_status() == 0
-    assert np.abs(got["logits"] - ref["logits"]).max() < LOGIT_TOL
+    assert set(calls) == set(ref_calls) and "conv_igemm_dma<64>" not in calls, (calls, ref_calls)
+    assert eng.take_status() == 0
+    assert np.array_equal(got["logits"], ref["logits"])
     for a, b in zip(got["denoised_wav"], ref["denoised_wav"]):
-        assert np.sqrt(np.mean((a - b) ** 2)) < 1e-5
+        assert np.array_equal(a, b)
+
+
+def test_separator_batch_of_128_ten_second_clips(eng_sep):
+    """The per-rank share of BASELINE configs[4] (separator, 1,024 clips over 8 GPUs = 128 x 10 s per GPU,
+    SS/apply.py:288-397) in ONE nhans_enhance_clips call: 127,744 frame windows, 34 chunks.  16 distinct speaker
+    mixtures repeated 8 times, the golden clip of case_separator10s among them: its golden frames at three batch
+    positions, every repetition bit-identical to the first (the chunk phase differs per repetition), everything
+    finite, no f16 saturation, and single-clip runs equal to their rows of the batch."""
+    eng_sep.set_precision("f16x3")
+    g = load_case("case_separator10s")
+
+    def sep_clip(cid):
+        return (apply.trim_to_frames(apply.normalise(synth.mixture(cid, 10.0))),
+                apply.normalise(synth.speaker_context(cid, low=True)),      # interferer (--neg) -> noise context
+                apply.normalise(synth.speaker_context(cid, low=False)))     # target (--pos) -> clean context
+    distinct = [sep_clip(5)] + [sep_clip(600 + i) for i in range(1, 16)]     # clip 5 = the golden one
+    clips = [distinct[i % 16] for i in range(128)]
+    mixes, cas, cbs = [list(x) for x in zip(*clips)]
+    mix_t, mix_off = eng_sep._dev(mixes)
+    ca_t, ca_off = eng_sep._dev(cas)
+    cb_t, cb_off = eng_sep._dev(cbs)
+    res = eng_sep.enhance_device(mix_t, mix_off, ca_t, ca_off, cb_t, cb_off, want_mixed=True, taps=True)
+    assert eng_sep.take_status() == 0
+    lg = res["logits"].view(128, 998, 201)
+    den = res["denoised_wav"].view(128, 159920)
+    assert bool(torch.isfinite(lg).all()) and bool(torch.isfinite(den).all())
+    emb = res["emb"].view(2, 128, 512)
+    assert float((emb[0, 0].cpu() - torch.from_numpy(g["emb_a"])).abs().max()) < 1e-4
+    assert float((emb[1, 0].cpu() - torch.from_numpy(g["emb_b"])).abs().max()) < 1e-4
+    gl = torch.from_numpy(g["logits"]).to(lg.device)
+    fr = torch.from_numpy(g["frames"].astype(np.int64)).to(lg.device)
+    for pos in (0, 48, 112):                                       # golden clip = every 16th
+        assert float((lg[pos][fr] - gl).abs().max()) < 5 * LOGIT_TOL, pos
+    for rep in range(1, 8):                                        # 998*16 % 3776 != 0: another chunk phase each time
+        assert torch.equal(lg[16 * rep:16 * rep + 16], lg[:16]), rep
+        assert torch.equal(den[16 * rep:16 * rep + 16], den[:16]), rep
+        assert torch.equal(emb[:, 16 * rep:16 * rep + 16], emb[:, :16]), rep
+    for i in (0, 7, 15):
+        single = eng_sep.enhance([mixes[i]], [cas[i]], [cbs[i]], want_mixed=False, taps=True)
+        assert np.array_equal(single["logits"], lg[i].cpu().numpy()), i
+        assert np.array_equal(single["denoised_wav"][0], den[i].cpu().numpy()), i
+    rt = res["mixed_wav"].view(128, 159920)
+    for i in (3, 127):
+        x = torch.from_numpy(mixes[i]).to(rt.device)
+        assert float((rt[i][240:-240] - x[240:-240]).abs().max()) < 2e-4
 
 
 @pytest.mark.parametrize("prec", ["f32", "f16x3"])

@@ -415,3 +415,23 @@ def test_bench_device_sampler_degrades_to_none_and_reads_hwmon(tmp_path, monkeyp
     st = s.stop()
     assert st["samples"] >= 2 and abs(st["sclk_mhz_mean"] - 1950.0) < 1e-6
     assert abs(st["socket_power_w_mean"] - 1336.0) < 1e-6 and st["power_cap_w"] == 1400.0
+
+
+def test_bench_gpus_flag_is_honoured_or_refused(monkeypatch, capfd):
+    import sys
+    """bench.py --gpus N: under a launcher (WORLD_SIZE set) a different N is an error (exit 2) instead of a silently
+    different run; without a launcher N > 1 starts N rank processes and the exit code is non-zero when a rank fails
+    (here: no HIP device, so every rank does)."""
+    sys.path.insert(0, ROOT)
+    import bench
+    monkeypatch.setenv("WORLD_SIZE", "1")
+    monkeypatch.setenv("RANK", "0")
+    assert bench.main(["--gpus", "8"]) == 2
+    assert "WORLD_SIZE=1" in capfd.readouterr().err
+    import torch
+    if torch.cuda.device_count() > 0:
+        return                                   # (the GPU suite runs the two-rank launch for real)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        monkeypatch.delenv(k, raising=False)
+    assert bench.main(["--gpus", "2", "--clips-per-gpu", "1", "--seconds", "1", "--steps", "1", "--warmup", "0"]) == 1
+    assert "rank(s) failed" in capfd.readouterr().err

@@ -9,7 +9,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import nhans_amd  # noqa: E402,F401
-from nhans_amd import engine, synth  # noqa: E402
+from nhans_amd import engine, hip, synth  # noqa: E402
 from nhans_amd.apply import normalise, trim_to_frames  # noqa: E402
 
 
@@ -18,6 +18,9 @@ def main():
     clips = int(sys.argv[2]) if len(sys.argv) > 2 else 2
     for prec, opts in (("f16x3", {}), ("f16x3", {"quad_workgroups": 1}), ("f32", {})):
         eng = engine.Engine("denoiser", precision=prec)
+        if opts and not hip.ab_build(eng.handle):   # quad_workgroups needs a `make AB=1` library
+            eng.close()
+            continue
         for k, v in opts.items():
             eng.set_option(k, v)
         mixes = [trim_to_frames(normalise(synth.mixture(i, 10.0 if i % 2 == 0 else 3.7))) for i in range(clips)]
