@@ -344,7 +344,11 @@ double launch_conv_igemm(const ConvArgs& a0, hipStream_t s, const char** kernel)
         // (layers marked for grouped summation / split-K always take the LDS-DMA kernel, whatever the
         // launch size: the choice must not depend on the batch)
         const bool halo_ok = a.variant >= 2 && a.kgroup >= 0;
-        if (halo_ok && !wide && a.variant == 2 && conv_igemm_halo_eligible(a)) {
+        if (halo_ok && conv_wino_eligible(a)) {
+            // stride-1 k x k convs of the stack: 1-D Winograd along W, 2.5 x fewer MFMAs (conv_wino.hip)
+            launch_conv_wino(a, s);
+            name = "conv_wino<64>";
+        } else if (halo_ok && !wide && a.variant == 2 && conv_igemm_halo_eligible(a)) {
             // the 64-channel stride-1 convs: 512-pixel tiles
             if (launch_conv_igemm_halo_persist(a, s)) name = "conv_igemm_halo_persist<64,512>";
             else { launch_conv_igemm_halo(a, s); name = "conv_igemm_halo<64,512>"; }

@@ -128,6 +128,7 @@ struct nhans_ctx {
     int ilv = 1;                // ConvArgs::ilv
     int persist = 0;            // ConvArgs::persist (measured slower: conv_igemm_halop.hip)
     int quad = 0;               // ConvArgs::quad
+    int wino = 0;               // ConvArgs::wino: 1-D Winograd form of the stride-1 stack convs (conv_wino.hip)
     long long* dbg = nullptr;   // NHANS_DEV builds: per-workgroup cycle stamps of the last conv launch
     int* status_dev = nullptr;  // sticky NHANS_STATUS_* bits set by kernels (nhans_take_status)
     // ordering of consecutive calls that share the workspace (see include/nhans_hip.h)
@@ -233,6 +234,7 @@ void fill_epilogue_defaults(nhans_ctx* c, ConvArgs& a) {
     a.ilv = c->ilv;
     a.persist = c->persist;
     a.quad = c->quad;
+    a.wino = c->wino; a.wino_u = nullptr; a.wino_ws = nullptr;
     a.kscratch = c->kscratch; a.kscratch_bytes = c->kscratch_bytes; a.kcounter = c->kcounter; a.kcounter_n = c->kcounter_n; a.kgroup = 0;
 }
 
@@ -389,6 +391,7 @@ float* run_stack_chunk(nhans_ctx* c, const float* logmag, const StackBufs& sb, i
             a.cb = cb1; a.cb_stride = c->cond_cols; a.img_clip = clipmap;
             a.tf = c->A(p + ".c1.tf");
             a.ws = c->WS(p + ".c1");
+            a.wino_u = c->A(p + ".c1.wino"); a.wino_ws = c->A(p + ".c1.wino.ws");
             run_conv(c, a, s);
         }
         ConvArgs a{};
@@ -399,6 +402,7 @@ float* run_stack_chunk(nhans_ctx* c, const float* logmag, const StackBufs& sb, i
         a.tf = c->A(p + ".c2.tf");
         a.idw = c->A(p + ".c2.idw");
         a.ws = c->WS(p + ".c2");
+        a.wino_u = c->A(p + ".c2.wino"); a.wino_ws = c->A(p + ".c2.wino.ws");
         float* out;
         if (b == 0) {                       // 1 -> 64 transform on the window image itself
             a.id_mode = 2; a.id = sb.xw; a.idH = g.hin; a.idW = g.win; a.idsh = 1; a.idsw = 1;
@@ -735,6 +739,7 @@ int nhans_set_option(nhans_ctx* c, const char* key, int64_t value) {
         if (!kAB && value == 3) return fail(NHANS_EINVAL, "conv_variant 3 exists only in a `make AB=1` build of the library");
         c->conv_variant = (int)value;
     }
+    else if (k == "winograd") c->wino = value != 0;
     else if (k == "ab_build") return kAB ? NHANS_OK : fail(NHANS_EINVAL, "not an AB=1 build");   // query: 0 = yes
     else if (k == "precision") {
         if (value != 0 && value != 1) return fail(NHANS_EINVAL, "precision must be 0 (f32) or 1 (f16x3)");

@@ -14,6 +14,7 @@ u64 total_bytes}, then n_entries x {char name[48]; u64 offset; u64 nfloats}, the
 at 256-byte-aligned offsets.
 """
 import struct
+from fractions import Fraction
 
 import numpy as np
 
@@ -94,6 +95,113 @@ def pack_igemm_h3(wkn, scale, npad=None):
         parts.append(a.transpose(0, 4, 1, 2, 5, 3))          # chunk, nt, s, g8, col, e
     p = np.stack(parts, axis=3)                               # chunk, nt, s, h, g8, col, e
     return np.ascontiguousarray(p).reshape(-1).view(np.float32)
+
+
+# ------------------------------------------------------------------------------ 1-D Winograd along W
+# conv_wino.hip runs the stride-1 k x k convs of the stack as F(m, k) along the image width, plain
+# accumulation over the filter rows and the channels: per tile of m output columns the 8 transformed
+# positions V_p = sum_x BT[p][x] d[x] of its 8 input columns are multiplied with the transformed
+# filter U_p[kh] = sum_kw G[p][kw] w[kh][kw] -- 8*kh instead of m*k*kh products per channel pair
+# (m = 5, k = 4: 2.5 x fewer; m = 6, k = 3: 2.25 x fewer) -- and Y = AT M gives the m outputs.
+# Interpolation points 0, +-1, +-2, +-1/2 and infinity (8 positions for either filter width, so that
+# each of the 8 MFMA waves of a workgroup owns one position); tests/winograd_probe.py is the accuracy gate.
+WINO_POINTS = (0, 1, -1, 2, -2, Fraction(1, 2), Fraction(-1, 2))
+WINO_N = 8
+
+
+def _solve_exact(rows, rhs):
+    """Gauss-Jordan over Fractions; the (consistent, full column rank) system rows . x = rhs."""
+    n = len(rows[0])
+    a = [list(map(Fraction, r)) + [Fraction(b)] for r, b in zip(rows, rhs)]
+    piv = 0
+    for col in range(n):
+        k = next((i for i in range(piv, len(a)) if a[i][col] != 0), None)
+        assert k is not None
+        a[piv], a[k] = a[k], a[piv]
+        a[piv] = [v / a[piv][col] for v in a[piv]]
+        for i in range(len(a)):
+            if i != piv and a[i][col] != 0:
+                f = a[i][col]
+                a[i] = [vi - f * vp for vi, vp in zip(a[i], a[piv])]
+        piv += 1
+    assert all(all(v == 0 for v in r) for r in a[piv:])
+    return [a[i][n] for i in range(n)]
+
+
+def wino_matrices(m, r):
+    """Cook-Toom matrices of F(m, r) on WINO_POINTS + infinity (m + r - 1 == 8), exact rationals as
+    float64: (AT [m, 8], G [8, r], BT [8, 8]) with y = AT ((G g) * (BT d)) for the m-output,
+    r-tap correlation y[i] = sum_k d[i + k] g[k]."""
+    n = m + r - 1
+    assert n == WINO_N
+    pts = [Fraction(p) for p in WINO_POINTS]
+    AT = [[(pts[j] ** i if j < n - 1 else Fraction(1 if i == m - 1 else 0)) for j in range(n)] for i in range(m)]
+    norm = []
+    for j in range(n - 1):
+        v = Fraction(1)
+        for k in range(n - 1):
+            if k != j:
+                v *= pts[j] - pts[k]
+        norm.append(v)
+    G = [[(pts[j] ** i / norm[j] if j < n - 1 else Fraction(1 if i == r - 1 else 0)) for i in range(r)] for j in range(n)]
+    BT = [[Fraction(0)] * n for _ in range(n)]
+    for col in range(n):
+        rows, rhs = [], []
+        for i in range(m):
+            for k in range(r):
+                rows.append([AT[i][j] * G[j][k] for j in range(n)])
+                rhs.append(1 if col == i + k else 0)
+        sol = _solve_exact(rows, rhs)
+        for j in range(n):
+            BT[j][col] = sol[j]
+    f = lambda M: np.array([[float(v) for v in row] for row in M], dtype=F64)
+    return f(AT), f(G), f(BT)
+
+
+# the input transform is hard-coded in conv_wino.hip (structured: 24 fused multiply-adds instead of 64)
+WINO_BT = np.array([[-1, 0, 5.25, 0, -5.25, 0, 1, 0],
+                    [0, 1, 1, -4.25, -4.25, 1, 1, 0],
+                    [0, -1, 1, 4.25, -4.25, -1, 1, 0],
+                    [0, 0.5, 0.25, -2.5, -1.25, 2, 1, 0],
+                    [0, -0.5, 0.25, 2.5, -1.25, -2, 1, 0],
+                    [0, 2, 4, -2.5, -5, 0.5, 1, 0],
+                    [0, -2, 4, 2.5, -5, -0.5, 1, 0],
+                    [0, -1, 0, 5.25, 0, -5.25, 0, 1]], dtype=F64)
+
+
+def wino_outputs(kw):
+    """outputs per tile for a kw-tap filter row (8 positions): 5 for 4 taps, 6 for 3."""
+    return WINO_N + 1 - kw
+
+
+def wino_eligible(kh, kw, sh, sw, cin, cout):
+    return (sh, sw) == (1, 1) and kw in (3, 4) and cin % 16 == 0 and cout % 64 == 0
+
+
+def pack_wino(w4):
+    """HWIO weights [KH, KW, C, N] (BatchNorm scale folded in) -> (packed U as a float32 view of
+    f16 bits, per-channel unscale vector).  U_p[kh][c][n] = sum_kw G[p][kw] w[kh][kw][c][n], scaled
+    per output channel by a power of two into [32, 64), split hi/lo; laid out
+    [N/64][p 8][C/16][KH][nt 2][h 2][lane 64][e 8]: lane l, element e of the fragment of
+    (64-channel block nb, position p, 16-channel chunk cc, filter row kh, 32-channel tile nt) holds
+    k = 16 cc + 8 (l >> 5) + e, column 64 nb + 32 nt + (l & 31) -- the wave that owns position p streams its
+    fragments strictly sequentially (conv_wino.hip)."""
+    kh, kw, c, n = w4.shape
+    assert c % 16 == 0 and n % 64 == 0
+    _, G, BT = wino_matrices(wino_outputs(kw), kw)
+    assert np.array_equal(BT, WINO_BT)
+    U = np.einsum("pk,hkcn->phcn", G, w4.astype(F64))              # [8, KH, C, N]
+    sc = col_scale(np.abs(U).reshape(-1, n))
+    Us = U * sc
+    hi = Us.astype(np.float16)
+    lo = (Us - hi.astype(F64)).astype(np.float16)
+    assert np.isfinite(hi).all()
+    parts = []
+    for a in (hi, lo):
+        a = a.reshape(WINO_N, kh, c // 16, 2, 8, n // 64, 2, 32)     # p, kh, cc, g8, e, nb, nt, col
+        parts.append(a.transpose(5, 0, 2, 1, 6, 3, 7, 4))            # nb, p, cc, kh, nt, g8, col, e
+    pk = np.stack(parts, axis=5)                                     # nb, p, cc, kh, nt, h, g8, col, e
+    return np.ascontiguousarray(pk).reshape(-1).view(np.float32), 1.0 / sc
 
 
 def _pad(v, npad):
@@ -178,6 +286,12 @@ def fold_arrays(W, kind, split_f16=True):
         else:
             out[p + ".c2.idw"] = sa
             emit(p + ".c2", [(p + ".c2.wpk", w2)])
+        if split_f16:
+            # 1-D Winograd form of the stride-1 convs without a `_transform` segment (conv_wino.hip)
+            for cv, scl, cin_, st in ((1, s1, g["cin"], (g["sh"], g["sw"])), (2, sa, c, (1, 1))):
+                w4 = w64("%s_conv%d/w" % (s, cv)) * scl
+                if cin_ == c and wino_eligible(g["kh"], g["kw"], st[0], st[1], cin_, c):
+                    out["%s.c%d.wino" % (p, cv)], out["%s.c%d.wino.ws" % (p, cv)] = pack_wino(w4)
         for cv, sc, sh, bias in ((1, s1, h1, 0.0), (2, sa, ha, extra_bias)):
             q = "%s_conv%d" % (s, cv)
             # time + frequency position terms in one [Ho*Wo, C] table (one coalesced read per output)
