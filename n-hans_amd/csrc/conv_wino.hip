@@ -47,7 +47,19 @@ constexpr int W_PLANE = W_NSLOT * 4 + 4;       // floats per plane (16 B per slo
 constexpr int W_VBUF = 32 * W_PLANE;           // floats per V buffer: 8 positions x {hi, lo} x 2 k-groups
 constexpr int W_LDM = 68;                      // epilogue: floats per tile-pixel row of an M_p tile (64 + 4)
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+
 __device__ __forceinline__ f16x8 as_h8(f32x4 v) { return __builtin_bit_cast(f16x8, v); }
+
+// value of a split-f16 element: (float)hi.half[SEL] + (float)lo.half[SEL] in ONE instruction (v_fma_mix_f32 reads
+// f16 halves of 32-bit registers as sources of an f32 fma; the compiler spends two conversions and an add on it)
+template <int SEL> __device__ __forceinline__ float unsplit_mix(float hi_pair, float lo_pair) {
+    float d;
+    if constexpr (SEL == 0) asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,1]" : "=v"(d) : "v"(hi_pair), "v"(lo_pair));
+    else asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[1,0,1] op_sel_hi:[1,0,1]" : "=v"(d) : "v"(hi_pair), "v"(lo_pair));
+    return d;
+}
 }  // namespace
 
 template <int KH, int MO>
@@ -79,87 +91,84 @@ __global__ void __launch_bounds__((WCW + WPW) * 64) conv_wino(const ConvArgs a) 
         const int ptid = tid - WCW * 64;
         const int nu = (TR + KH - 1) * TJ * 2;
         const bool active = ptid < nu;
-        const int kg = ptid & 1, slot = ptid >> 1;
+        const bool wave_active = (wave - WCW) * 64 < nu;              // (uniform: an idle wave only keeps the barriers)
+        const int kg = ptid & 1, slot = active ? ptid >> 1 : W_NSLOT - 1;   // idle lanes of a live wave write the spare last slot
         const int rs = slot / TJ, tj = slot - rs * TJ;
         const int hrow = r0 + rs - g.pt;
         const int wi0 = (j0 + tj) * MO - g.pl;
         const bool rowok = active && (unsigned)hrow < (unsigned)g.H;
-        // float index of pixel x's 16-byte hi piece of chunk 0 (split NHWC: a 32-channel group of a pixel is
-        // 16 floats of hi halfs followed by 16 floats of lo halfs), or the zero page for padding / unused slots
-        const float* px[8];
+        // Raw loads go through a buffer descriptor of the frame's image (base + 32-bit byte offset, 8 offset registers
+        // instead of 16 address pairs; an out-of-range offset returns zeros, which is exactly what padding columns,
+        // padding rows and unused slots need).  Split NHWC: a 32-channel group of a pixel is 64 B of hi halfs
+        // followed by 64 B of lo halfs.
+        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float*>(g.src) + (size_t)b * g.H * g.W * C, 0, g.H * g.W * C * 4, 0x00020000);
+        const unsigned voff0 = (unsigned)(((hrow * g.W + wi0) * C + kg * 4) * 4);
+        unsigned okmask = 0;
 #pragma unroll
-        for (int x = 0; x < 8; ++x) {
-            const bool ok = rowok && (unsigned)(wi0 + x) < (unsigned)g.W;
-            px[x] = ok ? g.src + ((size_t)((b * g.H + hrow) * g.W + wi0 + x) * C + kg * 4) : nullptr;
-        }
-        const float* const zp = a.zero + kg * 4;
+        for (int x = 0; x < 8; ++x) okmask |= (rowok && (unsigned)(wi0 + x) < (unsigned)g.W) ? 1u << x : 0u;
+        const unsigned pixb = (unsigned)C * 4u;
         float* const vw = smem + kg * W_PLANE + slot * 4;            // + buf*W_VBUF + (p*2 + h)*2*W_PLANE
-        bool sat = false;
 
         f32x4 rh[8], rl[8];
 #define NW_LOAD_RAW(CC)                                                                            \
     {                                                                                              \
-        const int co_ = ((CC) >> 1) * 32 + ((CC) & 1) * 8;                                         \
+        const int co_ = (((CC) >> 1) * 32 + ((CC) & 1) * 8) * 4;                                   \
         _Pragma("unroll") for (int x = 0; x < 8; ++x) {                                            \
-            const float* s_ = px[x] ? px[x] + co_ : zp;                                            \
-            rh[x] = *reinterpret_cast<const f32x4*>(s_);                                           \
-            rl[x] = *reinterpret_cast<const f32x4*>(s_ + (px[x] ? 16 : 0));                        \
+            const unsigned vo_ = ((okmask >> x) & 1) ? voff0 + x * pixb : 0x80000000u;             \
+            rh[x] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, vo_, co_, 0)); \
+            rl[x] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, vo_ + 64u, co_, 0)); \
         }                                                                                          \
     }
-        // BT, structured (fold.py: WINO_BT): even and odd parts of rows 1..6 share their sums
+        // BT, structured (fold.py: WINO_BT): even and odd parts of rows 1..6 share their sums.  Two channels at a
+        // time (f32x2: packed-f32 instructions).
 #define NW_TRANSFORM(D, V)                                                                         \
     {                                                                                              \
-        const float e1_ = __builtin_fmaf(-4.25f, D[4], D[2] + D[6]);                                \
-        const float o1_ = __builtin_fmaf(-4.25f, D[3], D[1] + D[5]);                                \
-        const float e2_ = __builtin_fmaf(0.25f, D[2], __builtin_fmaf(-1.25f, D[4], D[6]));          \
-        const float o2_ = __builtin_fmaf(0.5f, D[1], __builtin_fmaf(-2.5f, D[3], 2.f * D[5]));      \
-        const float e3_ = __builtin_fmaf(4.f, D[2], __builtin_fmaf(-5.f, D[4], D[6]));              \
-        const float o3_ = __builtin_fmaf(2.f, D[1], __builtin_fmaf(-2.5f, D[3], 0.5f * D[5]));      \
-        V[0] = __builtin_fmaf(5.25f, D[2] - D[4], D[6] - D[0]);                                     \
-        V[1] = e1_ + o1_;  V[2] = e1_ - o1_;                                                        \
-        V[3] = e2_ + o2_;  V[4] = e2_ - o2_;                                                        \
-        V[5] = e3_ + o3_;  V[6] = e3_ - o3_;                                                        \
-        V[7] = __builtin_fmaf(5.25f, D[3] - D[5], D[7] - D[1]);                                     \
+        const f32x2 e1_ = D[2] + D[6] - 4.25f * D[4];                                              \
+        const f32x2 o1_ = D[1] + D[5] - 4.25f * D[3];                                              \
+        const f32x2 e2_ = 0.25f * D[2] - 1.25f * D[4] + D[6];                                      \
+        const f32x2 o2_ = 0.5f * D[1] - 2.5f * D[3] + 2.f * D[5];                                  \
+        const f32x2 e3_ = 4.f * D[2] - 5.f * D[4] + D[6];                                          \
+        const f32x2 o3_ = 2.f * D[1] - 2.5f * D[3] + 0.5f * D[5];                                  \
+        V[0] = 5.25f * (D[2] - D[4]) + (D[6] - D[0]);                                              \
+        V[1] = e1_ + o1_;  V[2] = e1_ - o1_;                                                       \
+        V[3] = e2_ + o2_;  V[4] = e2_ - o2_;                                                       \
+        V[5] = e3_ + o3_;  V[6] = e3_ - o3_;                                                       \
+        V[7] = 5.25f * (D[3] - D[5]) + (D[7] - D[1]);                                              \
     }
 #define NW_PRODUCE(BUF)                                                                            \
     {                                                                                              \
         float* vb_ = vw + (BUF) * W_VBUF;                                                          \
-        _Pragma("unroll") for (int hq = 0; hq < 2; ++hq) {     /* 4 channels at a time */           \
-            f16x4 oh_[8], ol_[8];                                                                  \
-            _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                        \
-                float d_[8], v_[8];                                                                \
-                _Pragma("unroll") for (int x = 0; x < 8; ++x)                                      \
-                    d_[x] = (float)as_h8(rh[x])[hq * 4 + e] + (float)as_h8(rl[x])[hq * 4 + e];     \
-                NW_TRANSFORM(d_, v_)                                                               \
-                _Pragma("unroll") for (int p = 0; p < 8; ++p) {                                    \
-                    sat |= !(fabsf(v_[p]) < 65504.f);                                              \
-                    const float vc_ = fminf(fmaxf(v_[p], -65504.f), 65504.f);                      \
-                    oh_[p][e] = (_Float16)vc_;                                                     \
-                    ol_[p][e] = (_Float16)(vc_ - (float)oh_[p][e]);                                \
-                }                                                                                  \
+        /* two channels (one register of hi halfs, one of lo halfs per pixel) at a time; a V that leaves the f16     \
+           range becomes inf here and inf / NaN in this layer's output, where the epilogue raises the saturation flag */ \
+        _Pragma("unroll") for (int cp = 0; cp < 4; ++cp) {                                         \
+            f32x2 d_[8], v_[8];                                                                    \
+            _Pragma("unroll") for (int x = 0; x < 8; ++x) {                                        \
+                const float hp_ = rh[x][cp], lp_ = rl[x][cp];                                      \
+                d_[x] = f32x2{unsplit_mix<0>(hp_, lp_), unsplit_mix<1>(hp_, lp_)};                 \
             }                                                                                      \
-            if (active) {                                                                          \
-                _Pragma("unroll") for (int p = 0; p < 8; ++p) {                                    \
-                    *reinterpret_cast<f16x4*>(vb_ + (p * 2 + 0) * 2 * W_PLANE + hq * 2) = oh_[p];  \
-                    *reinterpret_cast<f16x4*>(vb_ + (p * 2 + 1) * 2 * W_PLANE + hq * 2) = ol_[p];  \
-                }                                                                                  \
+            NW_TRANSFORM(d_, v_)                                                                   \
+            _Pragma("unroll") for (int p = 0; p < 8; ++p) {                                        \
+                const f16x2 h_ = {(_Float16)v_[p].x, (_Float16)v_[p].y};                           \
+                const f16x2 l_ = {(_Float16)__builtin_fmaf((float)h_[0], -1.0f, v_[p].x),          \
+                                  (_Float16)__builtin_fmaf((float)h_[1], -1.0f, v_[p].y)};         \
+                *reinterpret_cast<f16x2*>(vb_ + (p * 2 + 0) * 2 * W_PLANE + cp) = h_;              \
+                *reinterpret_cast<f16x2*>(vb_ + (p * 2 + 1) * 2 * W_PLANE + cp) = l_;              \
             }                                                                                      \
+            __builtin_amdgcn_sched_barrier(0);                                                     \
         }                                                                                          \
     }
-        NW_LOAD_RAW(0)
-        NW_PRODUCE(0)
-        if (NC > 1) NW_LOAD_RAW(1)
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();                                   // V of chunk 0 is in LDS
-        for (int cc = 0; cc < NC; ++cc) {
-            if (cc + 1 < NC) {
+        // chunk cc+1 is transformed while the consumers multiply chunk cc; iteration -1 is the prologue
+        if (wave_active) NW_LOAD_RAW(0)
+#pragma unroll 1
+        for (int cc = -1; cc < NC; ++cc) {
+            if (wave_active && cc + 1 < NC) {
                 NW_PRODUCE((cc + 1) & 1)                                 // (its buffer was last read during chunk cc-1)
                 if (cc + 2 < NC) NW_LOAD_RAW(cc + 2)
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
         }
-        if (sat && a.sat) atomicOr(a.sat, kSatActivation);
         return;                                                         // the epilogue's barrier counts live waves only
 #undef NW_LOAD_RAW
 #undef NW_TRANSFORM
