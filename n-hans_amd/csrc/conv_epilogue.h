@@ -182,14 +182,9 @@ template <int IDM> struct Epi8Raw {               // what one pass has in flight
     int m, p;
 };
 
-// WINO > 0 (conv_wino.hip): `ct` holds the 8 transformed-domain accumulator tiles M_p[64 tile-pixels][LDC] of a 1-D
-// Winograd tile instead of one finished tile; local pixel p = i * 64 + q is output column i (< WINO) of tile-pixel q
-// and its accumulator is the output transform sum_p AT[i][p] * M_p[q] (PP == 64: i is the pass index, so the
-// coefficients are wave-uniform scalars).
-template <int PREC, int IDM, int HOIST, int PP, int PASSES, int LDC, int WINO = 0>
+template <int PREC, int IDM, int HOIST, int PP, int PASSES, int LDC>
 __device__ __forceinline__ void conv_epilogue_sweep8(const ConvArgs& a, const float* ct, const int4* rowinfo,
                                                      int prow, int c8, int n, long long* es = nullptr) {
-    static_assert(WINO == 0 || PP == 64, "Winograd sweep: one output column per pass");
     constexpr int GP = PASSES % 2 == 0 ? 2 : 1;
     constexpr int NG = PASSES / GP;
     const int f_tf = a.tf ? 1 : 0;
@@ -231,26 +226,11 @@ __device__ __forceinline__ void conv_epilogue_sweep8(const ConvArgs& a, const fl
             }
         }
     };
-    auto finish = [&](int g, Epi8Raw<IDM> (&r)[GP]) {
+    auto finish = [&](Epi8Raw<IDM> (&r)[GP]) {
 #pragma unroll
         for (int u = 0; u < GP; ++u) {
-            f32x4 av0, av1;
-            if constexpr (WINO == 0) {
-                av0 = *reinterpret_cast<const f32x4*>(ct + r[u].p * LDC + c8 * 8);
-                av1 = *reinterpret_cast<const f32x4*>(ct + r[u].p * LDC + c8 * 8 + 4);
-            } else {
-                const int i = g * GP + u;                      // output column within the tile == pass index
-                const float* mq = ct + prow * LDC + c8 * 8;
-                av0 = f32x4{0.f, 0.f, 0.f, 0.f};
-                av1 = av0;
-#pragma unroll
-                for (int pp = 0; pp < 8; ++pp) {
-                    const float co = a.wino_at[i][pp];
-                    const f32x4 cv = {co, co, co, co};
-                    av0 = fma4(cv, *reinterpret_cast<const f32x4*>(mq + pp * 64 * LDC), av0);
-                    av1 = fma4(cv, *reinterpret_cast<const f32x4*>(mq + pp * 64 * LDC + 4), av1);
-                }
-            }
+            const f32x4 av0 = *reinterpret_cast<const f32x4*>(ct + r[u].p * LDC + c8 * 8);
+            const f32x4 av1 = *reinterpret_cast<const f32x4*>(ct + r[u].p * LDC + c8 * 8 + 4);
             f32x4 i0 = {0.f, 0.f, 0.f, 0.f}, i1 = i0;
             if constexpr (IDM == 1) {
                 const f16x8 h = r[u].h, l = r[u].l;
@@ -285,13 +265,13 @@ __device__ __forceinline__ void conv_epilogue_sweep8(const ConvArgs& a, const fl
 #pragma unroll
     for (int g = 0; g < NG; g += 2) {
         if (g + 1 < NG) issue(g + 1, rb);
-        finish(g, ra);
+        finish(ra);
         if (kDev && es && g == 0) {                      // dev stamp: the first group is through
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             es[2] = (long long)__builtin_amdgcn_s_memtime();
         }
         if (g + 2 < NG) issue(g + 2, ra);
-        if (g + 1 < NG) finish(g + 1, rb);
+        if (g + 1 < NG) finish(rb);
     }
     if (sat && a.sat) atomicOr(a.sat, kSatActivation);
 }

@@ -47,6 +47,19 @@ constexpr int W_PLANE = W_NSLOT * 4 + 4;       // floats per plane (16 B per slo
 constexpr int W_VBUF = 32 * W_PLANE;           // floats per V buffer: 8 positions x {hi, lo} x 2 k-groups
 constexpr int W_LDM = 68;                      // epilogue: floats per tile-pixel row of an M_p tile (64 + 4)
 
+// split of two f32 values into packed f16 pairs: hi = RNE(v) (one v_cvt_pk_f16_f32), lo = RNE(v - hi) as one
+// v_fma_mixlo_f16 / v_fma_mixhi_f16 each (f16 source, f32 addend, f16 result into one half of the destination)
+__device__ __forceinline__ void split_pair(float vx, float vy, unsigned* hi, unsigned* lo) {
+    typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
+    const h2_t h = {(_Float16)vx, (_Float16)vy};
+    const unsigned hb = __builtin_bit_cast(unsigned, h);
+    unsigned l;
+    asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(l) : "v"(hb), "v"(vx));
+    asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(l) : "v"(hb), "v"(vy));
+    *hi = hb;
+    *lo = l;
+}
+
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 
@@ -62,12 +75,122 @@ template <int SEL> __device__ __forceinline__ float unsplit_mix(float hi_pair, f
 }
 }  // namespace
 
-template <int KH, int MO>
+// Output transform + fused block epilogue of one thread = (tile-pixel q, 8 channels).  `ct` holds the eight
+// transformed-domain accumulator tiles M_p[64 tile-pixels][W_LDM] (channel 8a + 4b + c of a row at float b*32 + a*4 + c:
+// the eight threads of a tile-pixel read 128 contiguous bytes at a time).  The thread reads its 8 x 8 values ONCE and
+// forms all MO output columns Y_i = sum_p AT[i][p] M_p with the shared sums of the +-1, +-2, +-1/2 point pairs
+// (18 instead of 8*MO operations per channel); local pixel i*64 + q is output column i of tile-pixel q.  The global
+// loads of every column (position table, residual) are in flight before the LDS reads start: one memory round trip.
+// IDM: 0 no residual, 1 split-NHWC tensor, 3 one-channel image.
+template <int IDM, int MO>
+__device__ __forceinline__ void wino_sweep(const ConvArgs& a, const float* ct, const int4* rowinfo, int q, int c8, int n,
+                                           long long* es) {
+    const int f_tf = a.tf ? 1 : 0;
+    const float* __restrict__ tfp = a.tf ? a.tf : a.zero;
+    const int hoff = (n >> 5) * 64 + (n & 31);                 // half index inside a split-NHWC pixel
+    const float lo_clamp = a.relu ? 0.f : -3.0e38f;
+    bool sat = false;
+
+    // The residual (HBM: ~2,500 cycles under load) of the first four columns is requested before the LDS reads of the
+    // output transform start, the rest four columns ahead -- two memory round trips per tile, not one per column; the position table (L2) follows
+    // one column ahead of its use.
+    Epi8Raw<IDM> r[MO];
+    int tfo[MO];
+    auto request = [&](int i) {
+        const int4 ri = rowinfo[i * 64 + q];
+        r[i].m = ri.z;
+        tfo[i] = (ri.y + n) * f_tf;
+        const int mc = ri.z < 0 ? 0 : ri.z;
+        if constexpr (IDM == 1) {
+            const _Float16* hp = reinterpret_cast<const _Float16*>(a.id + (size_t)mc * a.id_ld) + hoff;
+            r[i].h = *reinterpret_cast<const f16x8*>(hp);
+            r[i].l = *reinterpret_cast<const f16x8*>(hp + 32);
+        } else if constexpr (IDM == 3) {
+            r[i].sv = a.id[ri.w];
+        }
+    };
+    constexpr int AHEAD = 1;                                   // (more does not fit the register file)
+#pragma unroll
+    for (int i = 0; i < AHEAD; ++i) request(i);
+    __builtin_amdgcn_sched_barrier(0);
+    // two channels at a time (8 x 8-byte LDS reads): 16 live accumulator registers beside the 40 of the outputs
+    f32x2 y2[MO][4];
+#pragma unroll
+    for (int qt = 0; qt < 4; ++qt) {
+        f32x2 m[8];
+#pragma unroll
+        for (int pp = 0; pp < 8; ++pp)
+            m[pp] = *reinterpret_cast<const f32x2*>(ct + (pp * 64 + q) * W_LDM + (qt >> 1) * 32 + c8 * 4 + (qt & 1) * 2);
+        const f32x2 s12 = m[1] + m[2], d12 = m[1] - m[2], s34 = m[3] + m[4], d34 = m[3] - m[4], s56 = m[5] + m[6], d56 = m[5] - m[6];
+        y2[0][qt] = (m[0] + s12) + (s34 + s56);
+        y2[1][qt] = d12 + 2.f * d34 + 0.5f * d56;
+        y2[2][qt] = s12 + 4.f * s34 + 0.25f * s56;
+        y2[3][qt] = d12 + 8.f * d34 + 0.125f * d56;
+        if constexpr (MO == 5) {
+            y2[4][qt] = (s12 + m[7]) + 16.f * s34 + 0.0625f * s56;
+        } else {
+            y2[4][qt] = s12 + 16.f * s34 + 0.0625f * s56;
+            y2[MO - 1][qt] = (d12 + m[7]) + 32.f * d34 + 0.03125f * d56;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    if (kDev && es) es[2] = (long long)__builtin_amdgcn_s_memtime();
+    // (per-channel constants only now: they are not needed while the 8 x 8 accumulators are live)
+    const f32x4 ws0 = *reinterpret_cast<const f32x4*>(a.ws + n), ws1 = *reinterpret_cast<const f32x4*>(a.ws + n + 4);
+    f32x4 iw0 = {0.f, 0.f, 0.f, 0.f}, iw1 = iw0;
+    if constexpr (IDM != 0) { iw0 = *reinterpret_cast<const f32x4*>(a.idw + n); iw1 = *reinterpret_cast<const f32x4*>(a.idw + n + 4); }
+    const int cx = rowinfo[0].x;                               // one frame = one clip: one bias vector
+    const f32x4 hc0 = *reinterpret_cast<const f32x4*>(a.cb + cx + n), hc1 = *reinterpret_cast<const f32x4*>(a.cb + cx + n + 4);
+    r[0].t0 = *reinterpret_cast<const f32x4*>(tfp + tfo[0]);
+    r[0].t1 = *reinterpret_cast<const f32x4*>(tfp + tfo[0] + 4 * f_tf);
+#pragma unroll
+    for (int i = 0; i < MO; ++i) {
+        if (i + 1 < MO) {
+            r[i + 1].t0 = *reinterpret_cast<const f32x4*>(tfp + tfo[i + 1]);
+            r[i + 1].t1 = *reinterpret_cast<const f32x4*>(tfp + tfo[i + 1] + 4 * f_tf);
+        }
+        if (i + AHEAD < MO) request(i + AHEAD);
+        const f32x4 ya = {y2[i][0].x, y2[i][0].y, y2[i][1].x, y2[i][1].y}, yb = {y2[i][2].x, y2[i][2].y, y2[i][3].x, y2[i][3].y};
+        f32x4 i0 = {0.f, 0.f, 0.f, 0.f}, i1 = i0;
+        if constexpr (IDM == 1) {
+            const f16x8 h = r[i].h, l = r[i].l;
+            i0 = f32x4{(float)h[0] + (float)l[0], (float)h[1] + (float)l[1], (float)h[2] + (float)l[2], (float)h[3] + (float)l[3]};
+            i1 = f32x4{(float)h[4] + (float)l[4], (float)h[5] + (float)l[5], (float)h[6] + (float)l[6], (float)h[7] + (float)l[7]};
+        } else if constexpr (IDM == 3) {
+            i0 = f32x4{r[i].sv, r[i].sv, r[i].sv, r[i].sv};
+            i1 = i0;
+        }
+        const f32x4 r0 = epi_combine(ya, ws0, hc0, r[i].t0, iw0, i0);
+        const f32x4 r1 = epi_combine(yb, ws1, hc1, r[i].t1, iw1, i1);
+        if (r[i].m >= 0) {
+            float yc[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float v = fmaxf(e < 4 ? r0[e] : r1[e - 4], lo_clamp);
+                sat |= !(fabsf(v) < 65504.f);
+                yc[e] = fminf(fmaxf(v, -65504.f), 65504.f);
+            }
+            uint4 hb, lb;
+            split_pair(yc[0], yc[1], &hb.x, &lb.x);
+            split_pair(yc[2], yc[3], &hb.y, &lb.y);
+            split_pair(yc[4], yc[5], &hb.z, &lb.z);
+            split_pair(yc[6], yc[7], &hb.w, &lb.w);
+            _Float16* dst = reinterpret_cast<_Float16*>(a.out + (size_t)r[i].m * a.ldo) + hoff;
+            *reinterpret_cast<uint4*>(dst) = hb;
+            *reinterpret_cast<uint4*>(dst + 32) = lb;
+        }
+        __builtin_amdgcn_sched_barrier(0);                     // (keeps the table loads one column ahead, not five)
+    }
+    if (sat && a.sat) atomicOr(a.sat, kSatActivation);
+}
+
+template <int KH, int MO, int DBG = 0>      // DBG: dev tool, per-wave cycle stamps (tools/wino_phase_cycles.py)
 __global__ void __launch_bounds__((WCW + WPW) * 64) conv_wino(const ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-
+    long long dbg_entry = 0;
+    if constexpr (DBG) dbg_entry = (long long)__builtin_amdgcn_s_memtime();
     // XCD-aware, bijective remap of the linear workgroup id (each XCD owns a contiguous range of blocks)
     int L;
     {
@@ -92,10 +215,14 @@ __global__ void __launch_bounds__((WCW + WPW) * 64) conv_wino(const ConvArgs a) 
         const int nu = (TR + KH - 1) * TJ * 2;
         const bool active = ptid < nu;
         const bool wave_active = (wave - WCW) * 64 < nu;              // (uniform: an idle wave only keeps the barriers)
-        const int kg = ptid & 1, slot = active ? ptid >> 1 : W_NSLOT - 1;   // idle lanes of a live wave write the spare last slot
+        // k-group major: the lanes of a wave write consecutive slots of ONE plane (16-byte stride: at worst a 2-way
+        // bank conflict on the 8-byte stores); idle lanes of a live wave write the spare last slot
+        const int nsl = nu >> 1;
+        const int kg = active ? (ptid >= nsl ? 1 : 0) : 0, slot = active ? ptid - kg * nsl : W_NSLOT - 1;
+        __builtin_amdgcn_s_setprio(3);                                // the waves everybody waits for
         const int rs = slot / TJ, tj = slot - rs * TJ;
         const int hrow = r0 + rs - g.pt;
-        const int wi0 = (j0 + tj) * MO - g.pl;
+        const int wi0 = (j0 + tj) * MO - g.pl;   // (MO == a.wino_m & 255; DEV builds carry timing ablations above bit 8)
         const bool rowok = active && (unsigned)hrow < (unsigned)g.H;
         // Raw loads go through a buffer descriptor of the frame's image (base + 32-bit byte offset, 8 offset registers
         // instead of 16 address pairs; an out-of-range offset returns zeros, which is exactly what padding columns,
@@ -141,33 +268,60 @@ __global__ void __launch_bounds__((WCW + WPW) * 64) conv_wino(const ConvArgs a) 
         float* vb_ = vw + (BUF) * W_VBUF;                                                          \
         /* two channels (one register of hi halfs, one of lo halfs per pixel) at a time; a V that leaves the f16     \
            range becomes inf here and inf / NaN in this layer's output, where the epilogue raises the saturation flag */ \
-        _Pragma("unroll") for (int cp = 0; cp < 4; ++cp) {                                         \
-            f32x2 d_[8], v_[8];                                                                    \
-            _Pragma("unroll") for (int x = 0; x < 8; ++x) {                                        \
-                const float hp_ = rh[x][cp], lp_ = rl[x][cp];                                      \
-                d_[x] = f32x2{unsplit_mix<0>(hp_, lp_), unsplit_mix<1>(hp_, lp_)};                 \
+        _Pragma("unroll") for (int hq = 0; hq < 2; ++hq) {                                         \
+            uint2 oh_[8], ol_[8];                                                                  \
+            _Pragma("unroll") for (int ep = 0; ep < 2; ++ep) {                                     \
+                f32x2 d_[8], v_[8];                                                                \
+                _Pragma("unroll") for (int x = 0; x < 8; ++x) {                                    \
+                    const float hp_ = rh[x][hq * 2 + ep], lp_ = rl[x][hq * 2 + ep];                \
+                    d_[x] = f32x2{unsplit_mix<0>(hp_, lp_), unsplit_mix<1>(hp_, lp_)};             \
+                }                                                                                  \
+                NW_TRANSFORM(d_, v_)                                                               \
+                _Pragma("unroll") for (int p = 0; p < 8; ++p) {                                    \
+                    if (ep == 0) split_pair(v_[p].x, v_[p].y, &oh_[p].x, &ol_[p].x);               \
+                    else split_pair(v_[p].x, v_[p].y, &oh_[p].y, &ol_[p].y);                       \
+                }                                                                                  \
+                __builtin_amdgcn_sched_barrier(0);                                                 \
             }                                                                                      \
-            NW_TRANSFORM(d_, v_)                                                                   \
             _Pragma("unroll") for (int p = 0; p < 8; ++p) {                                        \
-                const f16x2 h_ = {(_Float16)v_[p].x, (_Float16)v_[p].y};                           \
-                const f16x2 l_ = {(_Float16)__builtin_fmaf((float)h_[0], -1.0f, v_[p].x),          \
-                                  (_Float16)__builtin_fmaf((float)h_[1], -1.0f, v_[p].y)};         \
-                *reinterpret_cast<f16x2*>(vb_ + (p * 2 + 0) * 2 * W_PLANE + cp) = h_;              \
-                *reinterpret_cast<f16x2*>(vb_ + (p * 2 + 1) * 2 * W_PLANE + cp) = l_;              \
+                *reinterpret_cast<uint2*>(vb_ + (p * 2 + 0) * 2 * W_PLANE + hq * 2) = oh_[p];      \
+                *reinterpret_cast<uint2*>(vb_ + (p * 2 + 1) * 2 * W_PLANE + hq * 2) = ol_[p];      \
             }                                                                                      \
             __builtin_amdgcn_sched_barrier(0);                                                     \
         }                                                                                          \
     }
         // chunk cc+1 is transformed while the consumers multiply chunk cc; iteration -1 is the prologue
+        long long dbg_setup = 0, dbg_landed = 0;
+        if constexpr (DBG) dbg_setup = (long long)__builtin_amdgcn_s_memtime() - dbg_entry;
         if (wave_active) NW_LOAD_RAW(0)
+        if constexpr (DBG) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            dbg_landed = (long long)__builtin_amdgcn_s_memtime() - dbg_entry;
+        }
+        long long dbg_prod = 0, dbg_bar = 0, dbg_first = 0;
 #pragma unroll 1
         for (int cc = -1; cc < NC; ++cc) {
+            long long t0 = 0, t1 = 0;
+            if constexpr (DBG) t0 = (long long)__builtin_amdgcn_s_memtime();
             if (wave_active && cc + 1 < NC) {
-                NW_PRODUCE((cc + 1) & 1)                                 // (its buffer was last read during chunk cc-1)
-                if (cc + 2 < NC) NW_LOAD_RAW(cc + 2)
+                if (!(DBG && (a.wino_m >> 8 & 4) && cc >= 0)) NW_PRODUCE((cc + 1) & 1)   // (its buffer was last read during chunk cc-1)
+                if (cc + 2 < NC && !(DBG && (a.wino_m >> 8 & 1))) NW_LOAD_RAW(cc + 2)
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if constexpr (DBG) t1 = (long long)__builtin_amdgcn_s_memtime();
             __builtin_amdgcn_s_barrier();
+            if constexpr (DBG) {
+                const long long t2 = (long long)__builtin_amdgcn_s_memtime();
+                if (cc < 0) dbg_first = t1 - t0; else { dbg_prod += t1 - t0; dbg_bar += t2 - t1; }
+            }
+        }
+        if constexpr (DBG) {                                            // [total, first chunk (load + transform), later chunks, barrier waits]
+            if (a.dbg && lane == 0) {
+                long long* d = a.dbg + ((size_t)blockIdx.x * (WCW + WPW) + wave) * 4;
+                d[0] = (long long)__builtin_amdgcn_s_memtime() - dbg_entry; d[1] = dbg_first; d[2] = dbg_prod; d[3] = dbg_bar;
+                long long* e = a.dbg + (size_t)(4 << 20) + ((size_t)blockIdx.x * (WCW + WPW) + wave) * 8;
+                e[0] = dbg_setup; e[1] = dbg_landed;
+            }
         }
         return;                                                         // the epilogue's barrier counts live waves only
 #undef NW_LOAD_RAW
@@ -191,8 +345,12 @@ __global__ void __launch_bounds__((WCW + WPW) * 64) conv_wino(const ConvArgs a) 
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[t][j][r] = 0.f;
 
-    f32x4 fb[2][2][2];                      // [ring][n-tile][hi|lo]
-    f32x4 fa[2][2][2];                      // [ring][m-tile][hi|lo]
+    // B (weights): ring of KH k-steps in registers, three k-steps ahead -- the fragments come straight from L2, and
+    // with one k-step in flight per wave the loop was bound by that latency (Little: 32 KB in flight per CU at ~800
+    // cycles = 29 B/clk against the 42 B/clk the MFMAs consume); A (V): read from LDS right before its k-step, the
+    // partner wave of the SIMD covers the LDS latency.
+    f32x4 fb[KH][2][2];                     // [ring][n-tile][hi|lo]
+    f32x4 fa[2][2];                         // [m-tile][hi|lo]
 #define NW_LOAD_B(RING, KS)                                                                        \
     {                                                                                              \
         const float* u_ = ub + (size_t)((KS) < nks ? (KS) : nks - 1) * 1024;                       \
@@ -200,39 +358,48 @@ __global__ void __launch_bounds__((WCW + WPW) * 64) conv_wino(const ConvArgs a) 
             _Pragma("unroll") for (int h = 0; h < 2; ++h)                                          \
                 fb[RING][j][h] = *reinterpret_cast<const f32x4*>(u_ + (j * 2 + h) * 256);          \
     }
-#define NW_READ_A(RING, BUF, KHI)                                                                  \
+#define NW_READ_A(BUF, KHI)                                                                        \
     {                                                                                              \
         const float* v_ = smem + (BUF) * W_VBUF + aoff + (KHI) * TJ * 4;                           \
         _Pragma("unroll") for (int t = 0; t < 2; ++t) {                                            \
-            fa[RING][t][0] = *reinterpret_cast<const f32x4*>(v_ + t * 128);                        \
-            fa[RING][t][1] = *reinterpret_cast<const f32x4*>(v_ + t * 128 + 2 * W_PLANE);          \
+            fa[t][0] = *reinterpret_cast<const f32x4*>(v_ + t * 128);                              \
+            fa[t][1] = *reinterpret_cast<const f32x4*>(v_ + t * 128 + 2 * W_PLANE);                \
         }                                                                                          \
     }
-#define NW_MFMA(RA, RB)                                                                            \
+#define NW_MFMA(RB)                                                                                \
     {                                                                                              \
         _Pragma("unroll") for (int pr = 0; pr < 3; ++pr)                                           \
             _Pragma("unroll") for (int t = 0; t < 2; ++t)                                          \
                 _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                    \
-                    const f16x8 a_ = as_h8(pr == 0 ? fa[RA][t][1] : fa[RA][t][0]);                 \
+                    const f16x8 a_ = as_h8(pr == 0 ? fa[t][1] : fa[t][0]);                         \
                     const f16x8 b_ = as_h8(pr == 1 ? fb[RB][j][1] : fb[RB][j][0]);                 \
                     acc[t][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b_, a_, acc[t][j], 0, 0, 0); \
                 }                                                                                  \
     }
-    static_assert(KH % 2 == 0, "the two-deep operand rings assume an even number of filter rows per chunk");
+    static_assert(KH == 4, "the weight ring is indexed by the filter row");
     NW_LOAD_B(0, 0)
+    NW_LOAD_B(1, 1)
+    NW_LOAD_B(2, 2)
+    long long dbg_setup = 0;
+    if constexpr (DBG) dbg_setup = (long long)__builtin_amdgcn_s_memtime() - dbg_entry;
     __builtin_amdgcn_s_barrier();                                       // V of chunk 0 is in LDS
+    long long dbg_t0 = 0, dbg_bar = 0, dbg_t1 = 0;
+    if constexpr (DBG) dbg_t0 = (long long)__builtin_amdgcn_s_memtime();
     for (int cc = 0; cc < NC; ++cc) {
         const int buf = cc & 1;
-        NW_READ_A(0, buf, 0)
 #pragma unroll
         for (int kh = 0; kh < KH; ++kh) {
-            NW_LOAD_B((kh + 1) & 1, cc * KH + kh + 1)
-            if (kh + 1 < KH) NW_READ_A((kh + 1) & 1, buf, kh + 1)
-            NW_MFMA(kh & 1, kh & 1)
+            NW_READ_A(buf, kh)
+            NW_LOAD_B((kh + 3) & 3, cc * KH + kh + 3)
+            if (!(DBG && (a.wino_m >> 8 & 2))) NW_MFMA(kh)
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        long long tq = 0;
+        if constexpr (DBG) tq = (long long)__builtin_amdgcn_s_memtime();
         __builtin_amdgcn_s_barrier();
+        if constexpr (DBG) dbg_bar += (long long)__builtin_amdgcn_s_memtime() - tq;
     }
+    if constexpr (DBG) dbg_t1 = (long long)__builtin_amdgcn_s_memtime();
 #undef NW_LOAD_B
 #undef NW_READ_A
 #undef NW_MFMA
@@ -247,7 +414,9 @@ __global__ void __launch_bounds__((WCW + WPW) * 64) conv_wino(const ConvArgs a) 
 #pragma unroll
             for (int q4 = 0; q4 < 4; ++q4) {
                 const f32x4 v = {acc[t][j][4 * q4], acc[t][j][4 * q4 + 1], acc[t][j][4 * q4 + 2], acc[t][j][4 * q4 + 3]};
-                *reinterpret_cast<f32x4*>(ct + (p * 64 + t * 32 + (lane & 31)) * W_LDM + j * 32 + 8 * q4 + 4 * g8) = v;
+                // channel n = 8a + 4b + c of the 64 sits at float b*32 + a*4 + c of its row: the sweep thread of channel
+                // group a reads two 16-byte pieces, and eight such threads cover 128 contiguous bytes each time
+                *reinterpret_cast<f32x4*>(ct + (p * 64 + t * 32 + (lane & 31)) * W_LDM + g8 * 32 + (j * 4 + q4) * 4) = v;
             }
     // local pixel P = i*64 + q: output column i of tile-pixel q
     for (int P = tid; P < 64 * MO; P += WCW * 64) {
@@ -262,13 +431,28 @@ __global__ void __launch_bounds__((WCW + WPW) * 64) conv_wino(const ConvArgs a) 
         const int ids = (b * a.idH + hh * a.idsh) * a.idW + ww * a.idsw;
         rowinfo[P] = make_int4(clip * a.cb_stride, rem * a.N, ok ? m : -1, ids);
     }
+    long long es[3] = {0, 0, 0}, dbg_e0 = 0, dbg_e1 = 0;
+    if constexpr (DBG) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); dbg_e0 = (long long)__builtin_amdgcn_s_memtime(); }
     __syncthreads();
+    if constexpr (DBG) dbg_e1 = (long long)__builtin_amdgcn_s_memtime();
     const int c8 = tid & 7, prow8 = tid >> 3;
     const int n8 = nb * 64 + c8 * 8;
     switch (a.id_mode) {                                               // one frame = one clip: the bias is loaded once
-        case 0: conv_epilogue_sweep8<1, 0, 1, 64, MO, W_LDM, MO>(a, ct, rowinfo, prow8, c8, n8); break;
-        case 1: conv_epilogue_sweep8<1, 1, 1, 64, MO, W_LDM, MO>(a, ct, rowinfo, prow8, c8, n8); break;
-        default: conv_epilogue_sweep8<1, 3, 1, 64, MO, W_LDM, MO>(a, ct, rowinfo, prow8, c8, n8); break;
+        case 0: wino_sweep<0, MO>(a, ct, rowinfo, prow8, c8, n8, DBG ? es : nullptr); break;
+        case 1: wino_sweep<1, MO>(a, ct, rowinfo, prow8, c8, n8, DBG ? es : nullptr); break;
+        default: wino_sweep<3, MO>(a, ct, rowinfo, prow8, c8, n8, DBG ? es : nullptr); break;
+    }
+    if constexpr (DBG) {                                                // [K loop, prologue wait, epilogue, barrier waits in the loop]
+        const long long t_issued = (long long)__builtin_amdgcn_s_memtime();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (a.dbg && lane == 0) {
+            const long long t_end = (long long)__builtin_amdgcn_s_memtime();
+            long long* d = a.dbg + ((size_t)blockIdx.x * (WCW + WPW) + wave) * 4;
+            d[0] = dbg_t1 - dbg_t0; d[1] = dbg_t0 - dbg_entry; d[2] = t_end - dbg_t1; d[3] = dbg_bar;
+            // setup | epilogue from its start: M tiles in LDS | barrier passed | loads of all passes arrived, first pass stored | all stores issued | drained
+            long long* e = a.dbg + (size_t)(4 << 20) + ((size_t)blockIdx.x * (WCW + WPW) + wave) * 8;
+            e[0] = dbg_setup; e[1] = dbg_e0 - dbg_t1; e[2] = dbg_e1 - dbg_t1; e[3] = es[2] - dbg_t1; e[4] = t_issued - dbg_t1; e[5] = t_end - dbg_t1;
+        }
     }
 }
 
@@ -290,12 +474,12 @@ void wino_block(int Ho, int ntile, int KH, int* tr, int* tj) {
         }
 }
 
-template <int KH, int MO> void launch_wino_t(const ConvArgs& a, hipStream_t s) {
+template <int KH, int MO, int DBG = 0> void launch_wino_t(const ConvArgs& a, hipStream_t s) {
     static unsigned long long attr_devices = 0;
-    set_max_dynamic_lds(reinterpret_cast<const void*>(&conv_wino<KH, MO>), kWinoLds, &attr_devices, "conv_wino");
+    set_max_dynamic_lds(reinterpret_cast<const void*>(&conv_wino<KH, MO, DBG>), kWinoLds, &attr_devices, "conv_wino");
     const int frames = a.M / (a.Ho * a.Wo);
     const int grid = frames * a.wino_nrb * a.wino_ncb * (a.N / 64);
-    NHANS_LAUNCH("conv_wino", (conv_wino<KH, MO>), dim3(grid), dim3((WCW + WPW) * 64), kWinoLds, s, a);
+    NHANS_LAUNCH("conv_wino", (conv_wino<KH, MO, DBG>), dim3(grid), dim3((WCW + WPW) * 64), kWinoLds, s, a);
 }
 }  // namespace
 
@@ -303,7 +487,7 @@ bool conv_wino_eligible(const ConvArgs& a) {
     const ConvSeg& g = a.seg[0];
     if (!a.wino || !a.wino_u || !a.wino_ws || a.prec != 1 || a.nseg != 1 || a.kgroup != 0) return false;
     if (g.KH != 4 || g.KW != g.KH || g.sh != 1 || g.sw != 1 || a.Wo != g.W || a.Ho != g.H) return false;   // (KH = 3: odd ring parity, not built yet)
-    if (g.C % 16 != 0 || a.N % 64 != 0 || a.Nreal != a.N || !a.out_split || !a.epi8 || a.aux) return false;
+    if (g.C % 16 != 0 || a.N % 64 != 0 || a.Nreal != a.N || !a.out_split || a.aux) return false;
     if (a.id_mode == 1 && !a.id_split) return false;
     if (a.M % (a.Ho * a.Wo) != 0) return false;
     // 32-bit element offsets inside the kernel
@@ -330,6 +514,11 @@ void launch_conv_wino(const ConvArgs& a0, hipStream_t s) {
             a.wino_at[i][p] = v;
         }
     a.ws = a.wino_ws;
+#ifdef NHANS_DEV
+    // NHANS_ABLATE (timing experiments, wrong results): 1 producers never reload, 2 consumers skip the MFMAs,
+    // 4 producers transform the first chunk only
+    if (a.dbg) { a.wino_m |= (dev_ablate() & 15) << 8; launch_wino_t<4, 5, 1>(a, s); return; }
+#endif
     launch_wino_t<4, 5>(a, s);
 }
 

@@ -128,7 +128,7 @@ struct nhans_ctx {
     int ilv = 1;                // ConvArgs::ilv
     int persist = 0;            // ConvArgs::persist (measured slower: conv_igemm_halop.hip)
     int quad = 0;               // ConvArgs::quad
-    int wino = 0;               // ConvArgs::wino: 1-D Winograd form of the stride-1 stack convs (conv_wino.hip)
+    int wino = 1;               // ConvArgs::wino: 1-D Winograd form of the stride-1 stack convs (conv_wino.hip)
     long long* dbg = nullptr;   // NHANS_DEV builds: per-workgroup cycle stamps of the last conv launch
     int* status_dev = nullptr;  // sticky NHANS_STATUS_* bits set by kernels (nhans_take_status)
     // ordering of consecutive calls that share the workspace (see include/nhans_hip.h)

@@ -439,14 +439,15 @@ def test_demo_and_eval_mode(_eng_d, _eng_s, weights_denoiser, tmp_path):
 
 @pytest.mark.parametrize("case, n", [("case_exp2", 308), ("case_synth10s", 998)])
 def test_winograd_convs_against_golden_logits(_eng_d, case, n):
-    """Option winograd = 1: the stride-1 4x4 convs of the stack run as 1-D Winograd F(5,4) along W
-    (conv_wino.hip, 2.5 x fewer MFMAs).  Same golden logits, same bar, on identical features; and the
-    profile shows that the Winograd kernel really ran."""
+    """Option winograd (default 1): the stride-1 4x4 convs of the stack run as 1-D Winograd F(5,4) along W
+    (conv_wino.hip, 2.5 x fewer MFMAs); 0 = the direct halo kernel for every conv.  Same golden logits, same
+    bar, on identical features, either way; and the profile shows that the Winograd kernel really ran."""
     _eng_d.set_precision("f16x3")
     g = load_case(case)
     lm = torch.from_numpy(g["logmag"]).cuda()
     ea = torch.from_numpy(g["emb_a"][None]).cuda()
     eb = torch.from_numpy(g["emb_b"][None]).cuda()
+    _eng_d.set_option("winograd", 0)
     direct = _eng_d.mask_net(lm, [0, n], ea, eb)[0].cpu().numpy()
     try:
         _eng_d.set_option("winograd", 1)
@@ -457,7 +458,7 @@ def test_winograd_convs_against_golden_logits(_eng_d, case, n):
         calls = {k: v["calls"] for k, v in _eng_d.profile().items()}
     finally:
         _eng_d.set_option("profile", 0)
-        _eng_d.set_option("winograd", 0)
+        _eng_d.set_option("winograd", 1)
     assert calls.get("conv_wino<64>", 0) >= 10, calls
     got = lg[g["frames"]] if "frames" in g else lg
     print("winograd vs golden %.3e, vs direct %.3e" % (np.abs(got - g["logits"]).max(), np.abs(lg - direct).max()))

@@ -1,0 +1,59 @@
+"""Dev tool: where a workgroup of the Winograd conv kernel (conv_wino.hip) spends its cycles, from s_memtime stamps of
+every wave (option debug_cycles_ptr; needs a developer build: `make -C n-hans_amd/csrc clean && make -C n-hans_amd/csrc DEV=1`):
+    python tools/wino_phase_cycles.py [block 1|3] [frames]"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import nhans_amd  # noqa: E402,F401
+from nhans_amd import engine, spec, synth  # noqa: E402
+from nhans_amd.apply import normalise, trim_to_frames  # noqa: E402
+
+
+def main():
+    block = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+    frames = int(sys.argv[2]) if len(sys.argv) > 2 else 998
+    eng = engine.Engine("denoiser", precision="f16x3")
+    eng.set_option("winograd", 1)
+    mix = trim_to_frames(normalise(synth.mixture(0, 10.0)))
+    lm, _ = eng.stft_features(torch.from_numpy(mix).cuda(), [0, len(mix)])
+    ea = torch.zeros(1, 512, device="cuda")
+    dbg = torch.zeros(8 * (1 << 20), dtype=torch.int64, device="cuda")
+    eng.set_option("debug_cycles_ptr", dbg.data_ptr())
+    eng.set_option("frames_per_chunk", frames)
+    for _ in range(2):
+        dbg.zero_()
+        eng.set_option("profile", 1)
+        eng.profile_reset()
+        eng.block_output(lm, [0, lm.shape[0]], ea, ea, 0, frames, block)
+        torch.cuda.synchronize()
+        prof = eng.profile()
+    g = spec.main_geometry()[block]
+    raw = dbg.cpu().numpy()
+    d = raw[:(4 << 20) // 48 * 48].reshape(-1, 12, 4).astype(np.float64)
+    nblk = int((d[:, 0, 0] > 0).sum())
+    d = d[:nblk]
+    m = d.mean(0)
+    nc = g["cout"] // 16
+    print("block %d conv2 (the last launch), %d workgroups, %d chunks of 16 channels x %d filter rows; MFMA floor per chunk %d cycles"
+          % (block, nblk, nc, g["kh"], g["kh"] * 12 * 32 * 2))
+    print("  profile:", {k: round(v["ms"], 3) for k, v in prof.items() if "wino" in k or "halo" in k})
+    for w in (0, 3, 7):
+        print("  consumer wave %d: waits for the first V %.0f | K loop %.0f (%.0f per chunk, of which barrier wait %.0f) | epilogue %.0f"
+              % (w, m[w, 1], m[w, 0], m[w, 0] / nc, m[w, 3] / nc, m[w, 2]))
+    e = raw[(4 << 20):(4 << 20) + nblk * 96].reshape(nblk, 12, 8).astype(np.float64).mean(0)
+    for w in (0, 7):
+        print("  consumer wave %d: setup %.0f | epilogue, cycles from its start: M tiles in LDS %.0f | barrier passed %.0f | first pass stored "
+              "%.0f | all stores issued %.0f | drained %.0f" % (w, e[w, 0], e[w, 1], e[w, 2], e[w, 3], e[w, 4], e[w, 5]))
+    print("  producer wave 8: setup %.0f | first raw tile landed %.0f (from kernel entry)" % (e[8, 0], e[8, 1]))
+    for w in range(8, 12):
+        print("  producer wave %d: alive %.0f | first chunk (load + transform) %.0f | later chunks %.0f each | barrier wait %.0f per chunk"
+              % (w, m[w, 0], m[w, 1], m[w, 2] / max(nc - 1, 1), m[w, 3] / nc))
+
+
+if __name__ == "__main__":
+    main()
