@@ -145,11 +145,11 @@ __device__ __forceinline__ void wino_sweep(const ConvArgs& a, const float* ct, c
     r[0].t1 = *reinterpret_cast<const f32x4*>(tfp + tfo[0] + 4 * f_tf);
 #pragma unroll
     for (int i = 0; i < MO; ++i) {
+        if (i + AHEAD < MO) request(i + AHEAD);                // (sets tfo[i + AHEAD]: before the table load below)
         if (i + 1 < MO) {
             r[i + 1].t0 = *reinterpret_cast<const f32x4*>(tfp + tfo[i + 1]);
             r[i + 1].t1 = *reinterpret_cast<const f32x4*>(tfp + tfo[i + 1] + 4 * f_tf);
         }
-        if (i + AHEAD < MO) request(i + AHEAD);
         const f32x4 ya = {y2[i][0].x, y2[i][0].y, y2[i][1].x, y2[i][1].y}, yb = {y2[i][2].x, y2[i][2].y, y2[i][3].x, y2[i][3].y};
         f32x4 i0 = {0.f, 0.f, 0.f, 0.f}, i1 = i0;
         if constexpr (IDM == 1) {
