@@ -324,12 +324,15 @@ def main(argv=None):
     if rank == 0:
         ms_step = 1e3 * dt / a.steps
         cap_tf = ceiling["sustained_tflops"] if ceiling else (F16_MFMA_AT_POWER_CAP_TFLOPS if a.precision == "f16x3" else None)
-        convs = {k: v for k, v in prof.items() if k.startswith("conv_igemm")}
+        convs = {k: v for k, v in prof.items() if k.startswith("conv_igemm") or k.startswith("conv_wino")}
         conv_ms = sum(v["ms"] for v in convs.values())
         conv_fl = sum(v["flops"] for v in convs.values())
         conv_calls = sum(v["calls"] for v in convs.values())
         peak = F16_MFMA_PEAK_TFLOPS if a.precision == "f16x3" else F32_MFMA_PEAK_TFLOPS
         tflops = conv_fl / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
+        # FLOPs the matrix cores executed: 3 f16 products per MAC in split mode, and 2.5 x fewer MACs than the direct
+        # form for the convs that run as 1-D Winograd (the library counts them per launch)
+        exec_tflops = sum(v.get("mfma_flops", 0.0) for v in convs.values()) / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
         # HBM bytes per conv launch: PMC counters cannot be read from inside this process; the committed
         # summary of the separate rocprofv3 --pmc passes over this very command (profiles/r02/README.md) is
         # quoted when the workload is the one it was collected on.
@@ -367,19 +370,20 @@ def main(argv=None):
             "x_realtime_per_gpu": audio_s * a.steps / dt,
             "status_flags": status,
             "device_state": device_state,
-            "roofline": {"bound": "mfma", "kernel": "conv_igemm_* (all implicit-GEMM conv launches of a step)",
+            "roofline": {"bound": "mfma", "kernel": "conv_igemm_* + conv_wino (all implicit-GEMM / Winograd conv launches of a step)",
+                         "achieved_basis": "algorithmic FLOPs of the DIRECT convolutions (2*M*K*N), whichever form runs them",
                          "achieved": tflops, "peak": peak, "unit": "TFLOP/s", "frac": tflops / peak,
                          "traffic": traffic, "traffic_source": traffic_src,
                          "launches": conv_calls, "kernel_ms_per_step": conv_ms,
                          "avg_launch_ms": conv_ms / conv_calls if conv_calls else None,
                          "algorithmic_gflop_per_launch": conv_fl / conv_calls / 1e9 if conv_calls else None,
-                         "executed_tflops": tflops * (3 if a.precision == "f16x3" else 1),
-                         "executed_frac": tflops * (3 if a.precision == "f16x3" else 1) / peak,
+                         "executed_tflops": exec_tflops,
+                         "executed_frac": exec_tflops / peak,
                          # what back-to-back f16 MFMAs on random register operands sustain at the socket power cap
                          # (tools/ubench/mfma_power.hip, profiles/r02/mfma_power_ceiling.txt); the datasheet peak is
                          # reached with all-zero operands only
                          "peak_at_power_cap": cap_tf,
-                         "executed_frac_of_peak_at_power_cap": tflops * 3 / cap_tf if cap_tf else None,
+                         "executed_frac_of_peak_at_power_cap": exec_tflops / cap_tf if cap_tf else None,
                          "peak_at_power_cap_source": ("measured in this run on this device: %.1f s of back-to-back "
                                                       "v_mfma_f32_32x32x16_f16 on random register operands after the timed "
                                                       "region (nhans_debug_mfma_ceiling)" % a.ceiling_seconds) if ceiling
@@ -390,7 +394,8 @@ def main(argv=None):
                          # the same algorithmic FLOPs over the UNPROFILED timed step (all kernels, launch gaps): lower bound
                          "step_level_tflops": step_flops / (ms_step * 1e-3) / 1e12 if step_flops else None,
                          "per_kernel": {k: {"ms": v["ms"], "launches": v["calls"],
-                                            "tflops": v["flops"] / (v["ms"] * 1e-3) / 1e12 if v["ms"] > 0 else None}
+                                            "tflops": v["flops"] / (v["ms"] * 1e-3) / 1e12 if v["ms"] > 0 else None,
+                                            "executed_tflops": v.get("mfma_flops", 0.0) / (v["ms"] * 1e-3) / 1e12 if v["ms"] > 0 else None}
                                         for k, v in sorted(convs.items())}},
             "hbm_kernels": {"stft_features_GBs": stft_gbs, "istft_ola_GBs": istft_gbs, "stft_context_features_GBs": stft_ctx_gbs,
                             "peak_GBs": HBM_PEAK_GBS,

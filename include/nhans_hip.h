@@ -96,6 +96,9 @@ void nhans_destroy(nhans_ctx* ctx);
  *          "consumer_interleave" (1, default: the MFMA waves of the halo kernel issue their LDS operand
  *           reads between their MFMAs, one behind each of the first MFMAs of a half-tap; 2: spread evenly over the
  *           half-tap; 0: read block then MFMA block -- identical bits, kept for A/B),
+ *          "winograd" (1, default: in split-f16 mode the stride-1 4x4 convs of the residual stack run as 1-D
+ *           Winograd convolutions F(5,4) along the image width, 2.5 x fewer matrix-core MACs -- conv_wino.hip;
+ *           0: the direct kernels for every conv -- results agree to ~1e-5 on the logits),
  *          The next three select kernels that exist only in a `make AB=1` build (the default library refuses them
  *          with NHANS_EINVAL; option "ab_build" returns NHANS_OK in such a build):
  *          "persistent_tiles" (0, default; 1: launches with >= 2 tiles per CU run the halo kernels as persistent
@@ -184,8 +187,10 @@ int nhans_debug_mfma_ceiling(double seconds, void* stream, double* sustained_tfl
  * verifies the 116 MB data shard with it (BundleEntryProto field 6 of the reference's shipped trained_model .index files). */
 uint32_t nhans_crc32c(uint32_t crc, const void* data_host, size_t nbytes);
 
-/* Profiling (option "profile" = 1): per-kernel launch counts, summed milliseconds and summed
- * algorithmic FLOPs / bytes since the last reset, as a JSON object written to buf.  Synchronises
+/* Profiling (option "profile" = 1): per-kernel launch counts, summed milliseconds, summed
+ * algorithmic FLOPs / bytes ("flops": 2*M*K*N of the DIRECT convolution whichever form runs it) and the
+ * FLOPs the matrix cores executed for them ("mfma_flops": three products per MAC in split-f16 mode, fewer
+ * MACs for the Winograd form) since the last reset, as a JSON object written to buf.  Synchronises
  * the recorded events.  Returns the number of bytes needed (excluding the NUL). */
 int nhans_profile_json(nhans_ctx* ctx, char* buf, size_t buflen);
 int nhans_profile_reset(nhans_ctx* ctx);

@@ -333,7 +333,7 @@ static void launch_t(const ConvArgs& a, hipStream_t s) {
     NHANS_LAUNCH("conv_igemm", (conv_igemm<BN, WM, WN, PREC, ABL>), dim3(grid), dim3(256), lds, s, a);
 }
 
-double launch_conv_igemm(const ConvArgs& a0, hipStream_t s, const char** kernel) {
+double launch_conv_igemm(const ConvArgs& a0, hipStream_t s, const char** kernel, double* mfma_flops) {
     ConvArgs a = a0;
     a.halo64_tile512 = a.variant == 2;
     double k = 0;
@@ -344,10 +344,12 @@ double launch_conv_igemm(const ConvArgs& a0, hipStream_t s, const char** kernel)
         // (layers marked for grouped summation / split-K always take the LDS-DMA kernel, whatever the
         // launch size: the choice must not depend on the batch)
         const bool halo_ok = a.variant >= 2 && a.kgroup >= 0;
+        bool wino = false;
         if (halo_ok && conv_wino_eligible(a)) {
             // stride-1 k x k convs of the stack: 1-D Winograd along W, 2.5 x fewer MFMAs (conv_wino.hip)
             launch_conv_wino(a, s);
             name = "conv_wino<64>";
+            wino = true;
         } else if (halo_ok && !wide && a.variant == 2 && conv_igemm_halo_eligible(a)) {
             // the 64-channel stride-1 convs: 512-pixel tiles
             if (launch_conv_igemm_halo_persist(a, s)) name = "conv_igemm_halo_persist<64,512>";
@@ -366,6 +368,7 @@ double launch_conv_igemm(const ConvArgs& a0, hipStream_t s, const char** kernel)
                                 : (wide ? "conv_igemm_dma<128>" : "conv_igemm_dma<64>");
         }
         if (kernel) *kernel = name;
+        if (mfma_flops) *mfma_flops = wino ? conv_wino_mfma_flops(a) : (a.prec == 1 ? 3.0 : 1.0) * 2.0 * (double)a.M * k * (double)a.N;
         return 2.0 * (double)a.M * k * (double)a.Nreal;
     }
     if (kernel) *kernel = wide ? "conv_igemm<128>" : "conv_igemm<64>";
@@ -389,6 +392,7 @@ double launch_conv_igemm(const ConvArgs& a0, hipStream_t s, const char** kernel)
     } else {
         if (a.N % 128 == 0) launch_t<128, 2, 2, 0>(a, s); else launch_t<64, 4, 1, 0>(a, s);
     }
+    if (mfma_flops) *mfma_flops = (a.prec == 1 ? 3.0 : 1.0) * 2.0 * (double)a.M * k * (double)a.N;
     return 2.0 * (double)a.M * k * (double)a.Nreal;
 }
 

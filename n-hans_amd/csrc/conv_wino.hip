@@ -81,7 +81,7 @@ template <int SEL> __device__ __forceinline__ float unsplit_mix(float hi_pair, f
 // forms all MO output columns Y_i = sum_p AT[i][p] M_p with the shared sums of the +-1, +-2, +-1/2 point pairs
 // (18 instead of 8*MO operations per channel); local pixel i*64 + q is output column i of tile-pixel q.  The global
 // loads of every column (position table, residual) are in flight before the LDS reads start: one memory round trip.
-// IDM: 0 no residual, 1 split-NHWC tensor, 3 one-channel image.
+// IDM: 0 no residual, 1 split-NHWC tensor, 2 f32 NHWC tensor, 3 one-channel image.
 template <int IDM, int MO>
 __device__ __forceinline__ void wino_sweep(const ConvArgs& a, const float* ct, const int4* rowinfo, int q, int c8, int n,
                                            long long* es) {
@@ -105,6 +105,10 @@ __device__ __forceinline__ void wino_sweep(const ConvArgs& a, const float* ct, c
             const _Float16* hp = reinterpret_cast<const _Float16*>(a.id + (size_t)mc * a.id_ld) + hoff;
             r[i].h = *reinterpret_cast<const f16x8*>(hp);
             r[i].l = *reinterpret_cast<const f16x8*>(hp + 32);
+        } else if constexpr (IDM == 2) {                       // (the two 16-byte pieces ride in the h / l slots)
+            const float* fp = a.id + (size_t)mc * a.id_ld + n;
+            r[i].h = __builtin_bit_cast(f16x8, *reinterpret_cast<const f32x4*>(fp));
+            r[i].l = __builtin_bit_cast(f16x8, *reinterpret_cast<const f32x4*>(fp + 4));
         } else if constexpr (IDM == 3) {
             r[i].sv = a.id[ri.w];
         }
@@ -156,6 +160,9 @@ __device__ __forceinline__ void wino_sweep(const ConvArgs& a, const float* ct, c
             const f16x8 h = r[i].h, l = r[i].l;
             i0 = f32x4{(float)h[0] + (float)l[0], (float)h[1] + (float)l[1], (float)h[2] + (float)l[2], (float)h[3] + (float)l[3]};
             i1 = f32x4{(float)h[4] + (float)l[4], (float)h[5] + (float)l[5], (float)h[6] + (float)l[6], (float)h[7] + (float)l[7]};
+        } else if constexpr (IDM == 2) {
+            i0 = __builtin_bit_cast(f32x4, r[i].h);
+            i1 = __builtin_bit_cast(f32x4, r[i].l);
         } else if constexpr (IDM == 3) {
             i0 = f32x4{r[i].sv, r[i].sv, r[i].sv, r[i].sv};
             i1 = i0;
@@ -439,7 +446,10 @@ __global__ void __launch_bounds__((WCW + WPW) * 64) conv_wino(const ConvArgs a) 
     const int n8 = nb * 64 + c8 * 8;
     switch (a.id_mode) {                                               // one frame = one clip: the bias is loaded once
         case 0: wino_sweep<0, MO>(a, ct, rowinfo, prow8, c8, n8, DBG ? es : nullptr); break;
-        case 1: wino_sweep<1, MO>(a, ct, rowinfo, prow8, c8, n8, DBG ? es : nullptr); break;
+        case 1:
+            if (a.id_split) wino_sweep<1, MO>(a, ct, rowinfo, prow8, c8, n8, DBG ? es : nullptr);
+            else wino_sweep<2, MO>(a, ct, rowinfo, prow8, c8, n8, DBG ? es : nullptr);
+            break;
         default: wino_sweep<3, MO>(a, ct, rowinfo, prow8, c8, n8, DBG ? es : nullptr); break;
     }
     if constexpr (DBG) {                                                // [K loop, prologue wait, epilogue, barrier waits in the loop]
@@ -488,31 +498,33 @@ bool conv_wino_eligible(const ConvArgs& a) {
     if (!a.wino || !a.wino_u || !a.wino_ws || a.prec != 1 || a.nseg != 1 || a.kgroup != 0) return false;
     if (g.KH != 4 || g.KW != g.KH || g.sh != 1 || g.sw != 1 || a.Wo != g.W || a.Ho != g.H) return false;   // (KH = 3: odd ring parity, not built yet)
     if (g.C % 16 != 0 || a.N % 64 != 0 || a.Nreal != a.N || !a.out_split || a.aux) return false;
-    if (a.id_mode == 1 && !a.id_split) return false;
+    if (a.id_mode == 1 && !a.id_split && (a.id_ld & 3)) return false;
     if (a.M % (a.Ho * a.Wo) != 0) return false;
     // 32-bit element offsets inside the kernel
     return (double)a.M * std::max(g.C, a.N) + 65536.0 < 2147483648.0;
 }
 
-void launch_conv_wino(const ConvArgs& a0, hipStream_t s) {
-    ConvArgs a = a0;
+static void wino_geometry(ConvArgs& a) {
     const ConvSeg& g = a.seg[0];
     a.wino_m = 9 - g.KW;                                               // 8 positions: 5 outputs for 4 taps, 6 for 3
     a.wino_ntile = (a.Wo + a.wino_m - 1) / a.wino_m;
     wino_block(a.Ho, a.wino_ntile, g.KH, &a.wino_tr, &a.wino_tj);
     a.wino_nrb = (a.Ho + a.wino_tr - 1) / a.wino_tr;
     a.wino_ncb = (a.wino_ntile + a.wino_tj - 1) / a.wino_tj;
-    // AT [m][8] on the points 0, 1, -1, 2, -2, 1/2, -1/2, infinity (fold.py: wino_matrices)
-    const float pts[7] = {0.f, 1.f, -1.f, 2.f, -2.f, 0.5f, -0.5f};
-    for (int i = 0; i < 6; ++i)
-        for (int p = 0; p < 8; ++p) {
-            float v = 0.f;
-            if (i < a.wino_m) {
-                if (p < 7) { v = 1.f; for (int e = 0; e < i; ++e) v *= pts[p]; }
-                else v = i == a.wino_m - 1 ? 1.f : 0.f;
-            }
-            a.wino_at[i][p] = v;
-        }
+}
+
+// MFMA FLOPs of the launch: every workgroup multiplies 8 positions x 64 tile-pixel slots (used or not) x 64 channels
+// over K = KH * C, three split-f16 products per MAC
+double conv_wino_mfma_flops(const ConvArgs& a0) {
+    ConvArgs a = a0;
+    wino_geometry(a);
+    const double wgs = (double)(a.M / (a.Ho * a.Wo)) * a.wino_nrb * a.wino_ncb * (a.N / 64);
+    return wgs * 8.0 * 64.0 * 64.0 * (double)(a.seg[0].KH * a.seg[0].C) * 2.0 * 3.0;
+}
+
+void launch_conv_wino(const ConvArgs& a0, hipStream_t s) {
+    ConvArgs a = a0;
+    wino_geometry(a);
     a.ws = a.wino_ws;
 #ifdef NHANS_DEV
     // NHANS_ABLATE (timing experiments, wrong results): 1 producers never reload, 2 consumers skip the MFMAs,

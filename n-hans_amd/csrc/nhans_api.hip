@@ -79,7 +79,7 @@ std::vector<BlockGeo> main_geometry() {        // SN/main.py:221-229
 
 struct ProfEntry {
     int calls = 0;
-    double flops = 0, bytes = 0;
+    double flops = 0, bytes = 0, mfma = 0;      // algorithmic FLOPs / bytes; FLOPs the matrix cores executed
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
     double ms = 0;
 };
@@ -209,7 +209,7 @@ struct Prof {
         b = take(c);
         (void)hipEventRecord(a, s);
     }
-    void done(double flops, double bytes, const char* late_name = nullptr) {
+    void done(double flops, double bytes, const char* late_name = nullptr, double mfma = 0) {
         if (!c->profile) return;
         if (late_name) e = &c->prof[late_name];
         if (!e) return;
@@ -218,6 +218,7 @@ struct Prof {
         e->calls += 1;
         e->flops += flops;
         e->bytes += bytes;
+        e->mfma += mfma;
     }
 };
 
@@ -259,8 +260,9 @@ void run_conv(nhans_ctx* c, const ConvArgs& a, hipStream_t s) {
     // profiled under the name of the kernel variant that ran (the variant is chosen per layer)
     Prof p(c, s, nullptr);
     const char* name = "conv_igemm";
-    double fl = launch_conv_igemm(a, s, &name);
-    p.done(fl, 0, name);
+    double mfma = 0;
+    double fl = launch_conv_igemm(a, s, &name, &mfma);
+    p.done(fl, 0, name, mfma);
 }
 
 // ---- embedding tower for `n` context images already in HBM ----------------------------------
@@ -337,11 +339,22 @@ size_t stack_buf_floats(const nhans_ctx* c, int64_t wf) {
 struct StackBufs {
     int* f_clip; int* f_t; int* f_T; int64_t* foff_dev; float* cb_all;
     float* xw; float* X; float* A; float* Y;
+    float* T;       // f32 output of a block's 1x1 `_transform` conv when its conv2 runs in Winograd form
 };
+
+// floats per frame window of StackBufs::T: the largest conv2 output among the channel-changing blocks whose conv2
+// has a Winograd form (4x4 filters: resblock2_1)
+size_t transform_buf_floats(const nhans_ctx* c, int64_t wf) {
+    size_t m = 0;
+    for (const auto& g : c->stack)
+        if (g.cin != g.cout && g.cin > 1 && g.kh == 4) m = std::max(m, (size_t)g.hout * g.wout * g.cout);
+    return m * (size_t)wf;
+}
 
 size_t stack_ws_bytes(const nhans_ctx* c, int64_t total, int nclips, int64_t wf) {
     size_t b = 3 * ws_size(total, 4) + ws_size(nclips + 1, 8) + ws_size((size_t)nclips * c->cond_cols, 4);
     b += ws_size((size_t)wf * kMixWin * kBins, 4) + 3 * ws_size(stack_buf_floats(c, wf), 4);
+    b += ws_size(transform_buf_floats(c, wf), 4);
     return b;
 }
 
@@ -352,6 +365,7 @@ void stack_take(nhans_ctx* c, int64_t total, int nclips, int64_t wf, StackBufs* 
     sb->xw = ws_take<float>(c, (size_t)wf * kMixWin * kBins);
     const size_t nb = stack_buf_floats(c, wf);
     sb->X = ws_take<float>(c, nb); sb->A = ws_take<float>(c, nb); sb->Y = ws_take<float>(c, nb);
+    sb->T = ws_take<float>(c, transform_buf_floats(c, wf));
 }
 
 // Runs blocks [0, upto) for frames [g0, g0+n); returns the buffer holding the last output.
@@ -410,6 +424,22 @@ float* run_stack_chunk(nhans_ctx* c, const float* logmag, const StackBufs& sb, i
         } else if (g.cin == g.cout) {       // identity shortcut, written in place over the block input
             a.id_mode = 1; a.id = x; a.id_ld = g.cout; a.id_split = c->prec;
             out = x;
+        } else if (c->wino && c->prec == 1 && g.kh == 4 && a.variant >= 2 && a.wino_u && a.wino_ws) {
+            // Channel-changing block whose conv2 has a Winograd form: the 1x1 strided `_transform` conv cannot ride in
+            // the K loop of the transformed domain, so it runs first on its own (3 % of the block's MACs) into an f32
+            // tensor that conv2's epilogue then adds like a residual (the bias of both is in conv2's bias row).
+            ConvArgs t{};
+            fill_epilogue_defaults(c, t);
+            t.nseg = 1;
+            t.seg[0] = make_seg(x, c->WP(p + ".c2.wpk_t"), g.hin, g.win, g.cin, 1, 1, g.sh, g.sw, false);
+            set_out_geometry(t, n, g.hout, g.wout, g.cout, g.cout, g.cout, sb.T);
+            t.cb = c->A("zero"); t.cb_stride = 0;
+            t.ws = c->WS(p + ".c2");            // (conv2 and the transform share one column scale: fold.py emit())
+            t.relu = 0; t.out_split = 0;
+            run_conv(c, t, s);
+            a.id_mode = 1; a.id = sb.T; a.id_ld = g.cout; a.id_split = 0;
+            a.idw = c->A("head.dense.idw");     // ones
+            out = y;
         } else {                            // 1x1 strided transform as extra K columns
             a.nseg = 2;
             a.seg[1] = make_seg(x, c->WP(p + ".c2.wpk_t"), g.hin, g.win, g.cin, 1, 1, g.sh, g.sw, false);
@@ -1022,9 +1052,9 @@ int nhans_profile_json(nhans_ctx* c, char* buf, size_t buflen) {
             c->event_pool.push_back(ev.second);
         }
         e.pending.clear();
-        char line[256];
-        snprintf(line, sizeof line, "%s\"%s\": {\"calls\": %d, \"ms\": %.6f, \"flops\": %.6e, \"bytes\": %.6e}",
-                 first ? "" : ", ", kv.first.c_str(), e.calls, e.ms, e.flops, e.bytes);
+        char line[384];
+        snprintf(line, sizeof line, "%s\"%s\": {\"calls\": %d, \"ms\": %.6f, \"flops\": %.6e, \"bytes\": %.6e, \"mfma_flops\": %.6e}",
+                 first ? "" : ", ", kv.first.c_str(), e.calls, e.ms, e.flops, e.bytes, e.mfma);
         js += line;
         first = false;
     }

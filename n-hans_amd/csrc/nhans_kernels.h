@@ -140,19 +140,21 @@ struct ConvArgs {
                            // the launcher turns -1 into the chunks per group
     // 1-D Winograd along W (conv_wino.hip).  Caller: wino_u / wino_ws (null = this conv has no Winograd form) and
     // wino on/off; the launcher fills in the rest: outputs per tile, tile-pixel block (rows x tiles, <= 64), blocks
-    // per frame, tiles per image row, and the output transform AT [m][8]
+    // per frame, tiles per image row
     const float* wino_u;
     const float* wino_ws;
     int wino;
     int wino_m, wino_tr, wino_tj, wino_nrb, wino_ncb, wino_ntile;
-    float wino_at[6][8];
     // 2-D pixel tiles (conv_igemm_halo2d.hip; filled in by its launcher): th x tw output pixels of one
     // image per workgroup, ntr x ntc tiles per image
     int t2_th, t2_tw, t2_ntr, t2_ntc;
 };
 
 // returns algorithmic FLOPs of the launch (2*M*K*Nreal); *kernel (optional) names the variant that ran
-double launch_conv_igemm(const ConvArgs& a, hipStream_t s, const char** kernel = nullptr);
+// *mfma_flops (optional): FLOPs the matrix cores actually execute for it -- 3 products per MAC in split-f16 mode,
+// and 8*KH instead of m*KW*KH products per tile for a conv that runs in its Winograd form
+double launch_conv_igemm(const ConvArgs& a, hipStream_t s, const char** kernel = nullptr, double* mfma_flops = nullptr);
+double conv_wino_mfma_flops(const ConvArgs& a);                 // conv_wino.hip
 void launch_conv_igemm_dma(const ConvArgs& a, hipStream_t s);   // conv_igemm_dma.hip
 bool conv_wino_eligible(const ConvArgs& a);                     // conv_wino.hip
 void launch_conv_wino(const ConvArgs& a, hipStream_t s);
