@@ -44,7 +44,7 @@ F16_MFMA_AT_POWER_CAP_TFLOPS = 1660.0   # round-2 measurement on another box (pr
                                         # --no-ceiling skips the live measurement (nhans_debug_mfma_ceiling) on THIS box
 HBM_PEAK_GBS = 8000.0             # spec; 6,290 GB/s is what a float4 copy achieves (same guide)
 HBM_ACHIEVABLE_GBS = 6290.0
-PMC_SUMMARY = os.path.join("profiles", "r02", "pmc_summary_bench_256clips.json")
+PMC_SUMMARY = os.path.join("profiles", "r03", "pmc_summary_bench_256clips.json")
 
 
 def parse(argv=None):
@@ -334,13 +334,13 @@ def main(argv=None):
         # form for the convs that run as 1-D Winograd (the library counts them per launch)
         exec_tflops = sum(v.get("mfma_flops", 0.0) for v in convs.values()) / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
         # HBM bytes per conv launch: PMC counters cannot be read from inside this process; the committed
-        # summary of the separate rocprofv3 --pmc passes over this very command (profiles/r02/README.md) is
+        # summary of the separate rocprofv3 --pmc passes over this very command (profiles/r03/README.md) is
         # quoted when the workload is the one it was collected on.
         traffic, traffic_src = None, None
         pmc = os.path.join(ROOT, PMC_SUMMARY)
         if (a.precision == "f16x3" and a.clips_per_gpu == 256 and a.seconds == 10.0 and a.kind == "denoiser"
                 and os.path.exists(pmc)):
-            rows = [v for k, v in json.load(open(pmc)).items() if "conv_igemm" in k]
+            rows = [v for k, v in json.load(open(pmc)).items() if "conv_igemm" in k or "conv_wino" in k]
             n = sum(v.get("dispatches_pass_c", 0) for v in rows)
             if n:
                 traffic = sum((v.get("derived_hbm_read_bytes_per_launch", 0.0) + v.get("derived_hbm_write_bytes_per_launch", 0.0))
