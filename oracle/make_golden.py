@@ -77,6 +77,46 @@ def copy_data_fixtures():
         os.chmod(os.path.join(OUT, dst), 0o644)
 
 
+DEMO = REF + "/DEMO_N-HANS/"
+# TensorFlow-written demo material (dumped by SN/main.py:296-306 / SS/main.py): first 8,400 samples (52 frames) of
+# `_mixed.wav` of six more examples of both models, and two (mixed, target, negNoise) triples of the denoiser
+DEMO_MIXED_MORE = [
+    "selective_noise_suppression/example5/82076_1_10_121-121726-0005_Imx5o81QWk0_120.000_3za2WvNjiBk_0.000_8_5_mixed.wav",
+    "Selective_Noise_Suppression_samples/snsExample3_4446-2275-0032_-ocADGlyaHc_30.000_6rNmM0Mt3zI_30.000_-3_0_mixed.wav",
+    "denoising/example3/82057_1_10_1462-170142-0022_Silent17_2ATRc7EonvI_30.000_5_8_mixed.wav",
+    "source_separation/example9/82024_1_0_00166_00221_0_mixed.wav",
+    "source_separation/example12/82024_1_0_00298_00095_0_mixed.wav",
+    "source_separation/example4/82024_1_0_00083_00062_5_mixed.wav",
+]
+DEMO_TRIPLES = [
+    "selective_noise_suppression/example5/82076_1_10_121-121726-0005_Imx5o81QWk0_120.000_3za2WvNjiBk_0.000_8_5_",
+    "Selective_Noise_Suppression_samples/snsExample2_4446-2273-0015_-NRx0SBMjo0_24.000_2yrL0F_0UGc_0.000_5_3_",
+]
+
+
+def demo_tf_fixtures(nsamp=8400):
+    """-> tests/golden/demo_tf_segments.npz: float32 segments of reference-shipped, TensorFlow-written wavs (data
+    only).  `mixed_<i>`: a `_mixed.wav` segment (STFT -> iSTFT fixed point in its interior); `triple_<i>_{mixed,
+    target,negNoise}`: the same samples of the three dumps of one utterance, which pin the reference's mixing
+    rule (SN/apply.py:96-102): target and noise are divided by the peak of the ALREADY normalised mixture (~1),
+    so  peak_raw * mixed == target + negNoise  with peak_raw != 1."""
+    from scipy.io import wavfile
+    out = {}
+    for i, rel in enumerate(DEMO_MIXED_MORE):
+        r, y = wavfile.read(DEMO + rel)
+        assert r == 16000 and y.dtype == np.float32 and len(y) >= nsamp
+        out["mixed_%d" % i] = y[:nsamp].copy()
+        out["mixed_%d_source" % i] = np.array(rel)
+    for i, base in enumerate(DEMO_TRIPLES):
+        for k in ("mixed", "target", "negNoise"):
+            r, y = wavfile.read(DEMO + base + k + ".wav")
+            assert r == 16000 and y.dtype == np.float32
+            out["triple_%d_%s" % (i, k)] = y[:nsamp].copy()
+        out["triple_%d_source" % i] = np.array(base)
+    np.savez_compressed(os.path.join(OUT, "demo_tf_segments.npz"), **out)
+    print("demo_tf_segments.npz:", os.path.getsize(os.path.join(OUT, "demo_tf_segments.npz")), "bytes")
+
+
 def new_cases_r2():
     """Cases added in round 2 (kept separate so they can be regenerated without the long exp2 run)."""
     Wd = weights.synthetic_weights("denoiser", 7)
@@ -156,8 +196,12 @@ def main():
     allres["lens"] = np.asarray(lens, dtype=np.int64)
     np.savez_compressed(OUT + "/case_ragged.npz", **allres)
     new_cases_r2()
+    demo_tf_fixtures()
     print("golden vectors written to", OUT)
 
 
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "demo":      # only the TensorFlow-written demo segments (seconds)
+        demo_tf_fixtures()
+    else:
+        main()

@@ -337,3 +337,21 @@ def test_saturation_is_detected_and_rerun_in_f32(lib_built, weights_denoiser):
     assert e16.precision == "f16x3"
     assert np.array_equal(got["logits"], ref["logits"])
     e16.close()
+
+
+def test_hip_round_trips_more_tensorflow_written_segments(eng):
+    """tests/golden/demo_tf_segments.npz (TensorFlow-written `_mixed.wav` dumps of both models, and the mixture of
+    the two triples): nhans_stft_features -> nhans_istft returns TF's samples in the interior; all eight as ONE
+    ragged batch."""
+    d = dict(np.load(os.path.join(GOLDEN, "demo_tf_segments.npz")))
+    sigs = [d["mixed_%d" % i] for i in range(6)] + [d["triple_%d_mixed" % i] for i in range(2)]
+    flat, off = eng._dev(sigs)
+    lm, ph = eng.stft_features(flat, off)
+    nfr = [spec.frames_for_samples(len(s))[1] for s in sigs]
+    foff = [0] + list(np.cumsum(nfr))
+    out, ooff = eng.istft(lm, ph, foff)
+    out = out.cpu().numpy()
+    for i, y in enumerate(sigs):
+        z = out[ooff[i]:ooff[i + 1]]
+        assert z.shape == y.shape
+        assert np.abs(z[240:-240] - y[240:-240]).max() < 2e-4, i

@@ -435,3 +435,59 @@ def test_bench_gpus_flag_is_honoured_or_refused(monkeypatch, capfd):
         monkeypatch.delenv(k, raising=False)
     assert bench.main(["--gpus", "2", "--clips-per-gpu", "1", "--seconds", "1", "--steps", "1", "--warmup", "0"]) == 1
     assert "rank(s) failed" in capfd.readouterr().err
+
+
+# ------------------------------------------------------------------------------ Winograd folding (conv_wino.hip)
+def test_winograd_matrices_are_exact_and_match_the_kernel_constants():
+    """fold.wino_matrices: Cook-Toom F(5,4) / F(6,3) on the points 0, +-1, +-2, +-1/2, infinity in exact rationals;
+    y = AT ((G g) * (BT d)) equals the correlation, BT is the table hard-coded in the kernel's input transform, AT is
+    the powers-of-the-points table its output transform spells out."""
+    from nhans_amd import fold
+    rng = np.random.default_rng(0)
+    for m, r in ((5, 4), (6, 3)):
+        AT, G, BT = fold.wino_matrices(m, r)
+        assert np.array_equal(BT, fold.WINO_BT) and AT.shape == (m, 8) and G.shape == (8, r)
+        pts = [0, 1, -1, 2, -2, 0.5, -0.5]
+        for i in range(m):
+            assert [AT[i, p] for p in range(7)] == [float(q) ** i for q in pts] and AT[i, 7] == (1.0 if i == m - 1 else 0.0)
+        g, d = rng.standard_normal(r), rng.standard_normal(8)
+        ref = np.array([d[i:i + r] @ g for i in range(m)])
+        assert np.abs(AT @ ((G @ g) * (BT @ d)) - ref).max() < 1e-13
+    assert fold.wino_outputs(4) == 5 and fold.wino_outputs(3) == 6
+
+
+def test_winograd_weight_pack_reproduces_the_direct_convolution():
+    """fold.pack_wino -> the fragment order conv_wino.hip streams ([N/64][p][C/16][KH][nt][hi|lo][lane][8]): unpack it
+    with the kernel's own index arithmetic, run the 1-D Winograd algorithm in float64 (V = BT d along W, M_p = sum over
+    filter rows and channels, Y = AT M) and compare with the direct SAME convolution."""
+    from nhans_amd import fold
+    rng = np.random.default_rng(1)
+    KH, C, N, H, W = 4, 32, 64, 7, 23
+    w4 = rng.standard_normal((KH, KH, C, N)) / np.sqrt(KH * KH * C)
+    x = rng.standard_normal((H, W, C))
+    pk, ws = fold.pack_wino(w4)
+    halfs = pk.view(np.float16).astype(np.float64).reshape(N // 64, 8, C // 16, KH, 2, 2, 64, 8)   # nb p cc kh nt h lane e
+    U = np.zeros((8, KH, C, N))
+    for lane in range(64):
+        for e in range(8):
+            # lane l, element e of fragment (nb, p, cc, kh, nt): k = 16 cc + 8 (l >> 5) + e, column 64 nb + 32 nt + (l & 31)
+            U[:, :, 8 * (lane >> 5) + e::16, (lane & 31)::32] = (halfs[:, :, :, :, :, 0, lane, e] + halfs[:, :, :, :, :, 1, lane, e]) \
+                .transpose(1, 3, 2, 0, 4).reshape(8, KH, C // 16, (N // 64) * 2)
+    U *= ws[None, None, None, :]                                   # undo the per-channel power-of-two scale
+    m = fold.wino_outputs(KH)
+    AT, G, BT = fold.wino_matrices(m, KH)
+    assert np.abs(U - np.einsum("pk,hkcn->phcn", G, w4)).max() < 1e-5 * np.abs(U).max()
+    pt, pl = spec.same_pad(H, KH, 1)[0], spec.same_pad(W, KH, 1)[0]
+    ntile = -(-W // m)
+    xp = np.zeros((H + KH - 1, ntile * m + 8, C))
+    xp[pt:pt + H, pl:pl + W] = x
+    out = np.zeros((H, ntile * m, N))
+    for j in range(ntile):
+        V = np.einsum("px,hxc->phc", BT, xp[:, j * m:j * m + 8])   # [8, H+KH-1, C]
+        M = sum(np.einsum("phc,pcn->phn", V[:, kh:kh + H], U[:, kh]) for kh in range(KH))
+        out[:, j * m:(j + 1) * m] = np.einsum("ip,phn->hin", AT, M)
+    ref = np.zeros((H, W, N))
+    for kh in range(KH):
+        for kw in range(KH):
+            ref += np.einsum("hwc,cn->hwn", xp[kh:kh + H, kw:kw + W], w4[kh, kw])
+    assert np.abs(out[:, :W] - ref).max() < 2e-6 * np.abs(ref).max() + 1e-6

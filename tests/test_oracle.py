@@ -164,3 +164,43 @@ def test_oracle_round_trips_a_tensorflow_written_waveform():
     assert np.abs(z[240:-240] - y[240:-240]).max() < 5e-5
     # TF's synthesis window leaves the partially covered edges attenuated: a second pass attenuates again
     assert np.abs(z[:100]).sum() < np.abs(y[:100]).sum() or np.abs(y[:100]).sum() == 0
+
+
+def _demo_segments():
+    return dict(np.load(os.path.join(GOLDEN, "demo_tf_segments.npz")))
+
+
+def test_oracle_round_trips_more_tensorflow_written_segments():
+    """Six more `_mixed.wav` dumps of the demo material (both models; first 52 frames each): the oracle's STFT ->
+    log-magnitude / phase -> iSTFT returns TensorFlow's samples in the interior."""
+    d = _demo_segments()
+    n = 0
+    while "mixed_%d" % n in d:
+        y = d["mixed_%d" % n]
+        assert y.dtype == np.float32 and (len(y) - 400) % 160 == 0
+        z = O.recover_samples(*O.logmag_phase(O.stft(y)))
+        assert np.abs(z[240:-240] - y[240:-240]).max() < 5e-5, str(d["mixed_%d_source" % n])
+        n += 1
+    assert n == 6
+
+
+def test_tensorflow_written_triples_pin_the_mixing_rule():
+    """SN/apply.py:96-102 divides target and noise by the peak of the ALREADY normalised mixture (~1), not by the raw
+    peak the mixture itself was divided by.  The reference's own dumps show it: peak_raw * mixed == target + negNoise
+    sample by sample (interior of the overlap-add), with peak_raw clearly not 1 -- and the oracle's domixing
+    reproduces exactly that relation (same rule, checked on synthetic signals)."""
+    d = _demo_segments()
+    for i in range(2):
+        m, t, n = (d["triple_%d_%s" % (i, k)].astype(np.float64) for k in ("mixed", "target", "negNoise"))
+        s, sl = t + n, slice(240, -240)
+        pk = float(s[sl] @ m[sl]) / float(m[sl] @ m[sl])
+        assert abs(pk - 1.0) > 1e-3, pk                                   # i.e. NOT normalised like the mixture
+        assert np.abs(pk * m[sl] - s[sl]).max() < 2e-5 * max(1.0, np.abs(s[sl]).max())
+    # the oracle's rule gives the same relation: target + neg signal == mixture * (raw peak / (max|mixed| + 1e-6))
+    clean = O.trim_to_frames(O.normalise(synth.mixture(21, 1.0)))
+    pos, neg = O.normalise(synth.noise_context(21, 1.0)), O.normalise(synth.speaker_context(21, 1.0))
+    mixed, target, kp, kn, pos_s, neg_s = O.domixing(clean, pos, neg, 5, 3)
+    raw = clean + np.float32(kp) * O._fit(pos, len(clean)) + np.float32(kn) * O._fit(neg, len(clean))
+    pk = (np.abs(raw).max() + 1e-6) / (np.abs(mixed).max() + 1e-6)
+    assert abs(pk - 1.0) > 1e-3
+    assert np.abs(pk * mixed.astype(np.float64) - (target.astype(np.float64) + neg_s)).max() < 1e-5
