@@ -46,6 +46,10 @@ constexpr int W_NSLOT = 96;                    // (row, tile) slots per plane: >
 constexpr int W_PLANE = W_NSLOT * 4 + 4;       // floats per plane (16 B per slot, 16 B of skew between planes)
 constexpr int W_VBUF = 32 * W_PLANE;           // floats per V buffer: 8 positions x {hi, lo} x 2 k-groups
 constexpr int W_LDM = 68;                      // epilogue: floats per tile-pixel row of an M_p tile (64 + 4)
+constexpr int W_RROWS = 12, W_RPX = 40;        // staged input tile of a chunk: rows (TR + KH - 1 <= 12) x pixels (TJ*m + 3 <= 40)
+constexpr int W_RKIND = W_RROWS * W_RPX * 4;   // floats per piece kind (hi|lo x k-group): one 16-byte piece per (row, pixel)
+constexpr int W_RAW = 4 * W_RKIND;             // floats per staged tile
+constexpr int W_RAW_BASE = 2 * W_VBUF;         // after the two V buffers
 
 // split of two f32 values into packed f16 pairs: hi = RNE(v) (one v_cvt_pk_f16_f32), lo = RNE(v - hi) as one
 // v_fma_mixlo_f16 / v_fma_mixhi_f16 each (f16 source, f32 addend, f16 result into one half of the destination)
@@ -95,11 +99,9 @@ __device__ __forceinline__ void wino_sweep(const ConvArgs& a, const float* ct, c
     // output transform start, the rest four columns ahead -- two memory round trips per tile, not one per column; the position table (L2) follows
     // one column ahead of its use.
     Epi8Raw<IDM> r[MO];
-    int tfo[MO];
     auto request = [&](int i) {
         const int4 ri = rowinfo[i * 64 + q];
         r[i].m = ri.z;
-        tfo[i] = (ri.y + n) * f_tf;
         const int mc = ri.z < 0 ? 0 : ri.z;
         if constexpr (IDM == 1) {
             const _Float16* hp = reinterpret_cast<const _Float16*>(a.id + (size_t)mc * a.id_ld) + hoff;
@@ -113,7 +115,7 @@ __device__ __forceinline__ void wino_sweep(const ConvArgs& a, const float* ct, c
             r[i].sv = a.id[ri.w];
         }
     };
-    constexpr int AHEAD = 1;                                   // (more does not fit the register file)
+    constexpr int AHEAD = 2;                                   // (three does not fit the register file)
 #pragma unroll
     for (int i = 0; i < AHEAD; ++i) request(i);
     __builtin_amdgcn_sched_barrier(0);
@@ -145,15 +147,16 @@ __device__ __forceinline__ void wino_sweep(const ConvArgs& a, const float* ct, c
     if constexpr (IDM != 0) { iw0 = *reinterpret_cast<const f32x4*>(a.idw + n); iw1 = *reinterpret_cast<const f32x4*>(a.idw + n + 4); }
     const int cx = rowinfo[0].x;                               // one frame = one clip: one bias vector
     const f32x4 hc0 = *reinterpret_cast<const f32x4*>(a.cb + cx + n), hc1 = *reinterpret_cast<const f32x4*>(a.cb + cx + n + 4);
-    r[0].t0 = *reinterpret_cast<const f32x4*>(tfp + tfo[0]);
-    r[0].t1 = *reinterpret_cast<const f32x4*>(tfp + tfo[0] + 4 * f_tf);
+    auto table = [&](int i) {                                  // position table of column i (L2-resident)
+        const int o = (rowinfo[i * 64 + q].y + n) * f_tf;
+        r[i].t0 = *reinterpret_cast<const f32x4*>(tfp + o);
+        r[i].t1 = *reinterpret_cast<const f32x4*>(tfp + o + 4 * f_tf);
+    };
+    table(0);
 #pragma unroll
     for (int i = 0; i < MO; ++i) {
-        if (i + AHEAD < MO) request(i + AHEAD);                // (sets tfo[i + AHEAD]: before the table load below)
-        if (i + 1 < MO) {
-            r[i + 1].t0 = *reinterpret_cast<const f32x4*>(tfp + tfo[i + 1]);
-            r[i + 1].t1 = *reinterpret_cast<const f32x4*>(tfp + tfo[i + 1] + 4 * f_tf);
-        }
+        if (i + AHEAD < MO) request(i + AHEAD);
+        if (i + 1 < MO) table(i + 1);
         const f32x4 ya = {y2[i][0].x, y2[i][0].y, y2[i][1].x, y2[i][1].y}, yb = {y2[i][2].x, y2[i][2].y, y2[i][3].x, y2[i][3].y};
         f32x4 i0 = {0.f, 0.f, 0.f, 0.f}, i1 = i0;
         if constexpr (IDM == 1) {
@@ -217,41 +220,73 @@ __global__ void __launch_bounds__((WCW + WPW) * 64) conv_wino(const ConvArgs a) 
 
     if (wave >= WCW) {
         // =========================================================================================
-        // Producers: thread = (slot, k-group): 8 input pixels x 8 channels of one (row, tile).
+        // Producers.  Wave 11 stages the input tile of a chunk in LDS by LDS-DMA: one 16-byte piece per (kind, row,
+        // pixel), kind = (hi|lo, k-group), lanes = consecutive pixels of a row, so that a wave-instruction touches 16
+        // cache lines instead of 64 -- the K loop of this kernel is bound by the CU's vector-memory request rate
+        // (per chunk 128 one-KB weight fragments for the consumers; per-thread 16-byte gathers for the tile cost as much
+        // again) -- and every pixel is fetched once although 1.6 tiles use it.  Padding pixels, padding rows and unused
+        // slots come from the zero page.  Waves 8-10 transform: thread = (slot, k-group) = 8 pixels x 8 channels.
         const int ptid = tid - WCW * 64;
-        const int nu = (TR + KH - 1) * TJ * 2;
+        const int nrows = TR + KH - 1;
+        __builtin_amdgcn_s_setprio(3);                                // the waves everybody waits for
+        if (wave == WCW + WPW - 1) {
+            constexpr int NDMA = W_RAW / 4 / 64;                      // 30 wave-instructions per tile
+            const int npx = TJ * MO + KH - 1;
+            unsigned goff[NDMA];
+#pragma unroll
+            for (int i = 0; i < NDMA; ++i) {
+                const int q = i * 64 + lane;
+                const int kind = q / (W_RROWS * W_RPX), rem = q - kind * (W_RROWS * W_RPX);
+                const int row = rem / W_RPX, px = rem - row * W_RPX;
+                const int hrow = r0 + row - g.pt, wcol = j0 * MO - g.pl + px;
+                const bool ok = row < nrows && px < npx && (unsigned)hrow < (unsigned)g.H && (unsigned)wcol < (unsigned)g.W;
+                // split NHWC: a 32-channel group of a pixel is 64 B of hi halfs followed by 64 B of lo halfs
+                goff[i] = ok ? (unsigned)(((hrow * g.W + wcol) * C) * 4 + (kind & 1) * 16 + (kind >> 1) * 64) : 0xFFFFFFFFu;
+            }
+            const char* const fb = reinterpret_cast<const char*>(g.src + (size_t)b * g.H * g.W * C);
+            const char* const zp = reinterpret_cast<const char*>(a.zero + lane * 4);
+#define NW_DMA(CC, BUF)                                                                            \
+    {                                                                                              \
+        const unsigned co_ = (unsigned)((((CC) >> 1) * 32 + ((CC) & 1) * 8) * 4);                  \
+        float* dst_ = smem + W_RAW_BASE + (BUF) * W_RAW;                                           \
+        _Pragma("unroll") for (int i = 0; i < NDMA; ++i) {                                         \
+            const char* s_ = goff[i] != 0xFFFFFFFFu ? fb + (goff[i] + co_) : zp;                   \
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)s_,   \
+                                             (__attribute__((address_space(3))) void*)(dst_ + i * 256), 16, 0, 0); \
+        }                                                                                          \
+    }
+            // iteration it: the tile of chunk it+2 (its buffer was last read by the transform of chunk it, one iteration ago)
+            NW_DMA(0, 0)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+#pragma unroll 1
+            for (int cc = -1; cc < NC; ++cc) {
+                if (cc + 2 < NC) NW_DMA(cc + 2, cc & 1)
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+            }
+            return;
+#undef NW_DMA
+        }
+        const int nu = nrows * TJ * 2;
         const bool active = ptid < nu;
         const bool wave_active = (wave - WCW) * 64 < nu;              // (uniform: an idle wave only keeps the barriers)
         // k-group major: the lanes of a wave write consecutive slots of ONE plane (16-byte stride: at worst a 2-way
-        // bank conflict on the 8-byte stores); idle lanes of a live wave write the spare last slot
+        // bank conflict on the 8-byte stores); idle lanes of a live wave read slot 0 and write the spare last slot
         const int nsl = nu >> 1;
-        const int kg = active ? (ptid >= nsl ? 1 : 0) : 0, slot = active ? ptid - kg * nsl : W_NSLOT - 1;
-        __builtin_amdgcn_s_setprio(3);                                // the waves everybody waits for
+        const int kg = active ? (ptid >= nsl ? 1 : 0) : 0, slot = active ? ptid - kg * nsl : 0;
         const int rs = slot / TJ, tj = slot - rs * TJ;
-        const int hrow = r0 + rs - g.pt;
-        const int wi0 = (j0 + tj) * MO - g.pl;   // (MO == a.wino_m & 255; DEV builds carry timing ablations above bit 8)
-        const bool rowok = active && (unsigned)hrow < (unsigned)g.H;
-        // Raw loads go through a buffer descriptor of the frame's image (base + 32-bit byte offset, 8 offset registers
-        // instead of 16 address pairs; an out-of-range offset returns zeros, which is exactly what padding columns,
-        // padding rows and unused slots need).  Split NHWC: a 32-channel group of a pixel is 64 B of hi halfs
-        // followed by 64 B of lo halfs.
-        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
-            const_cast<float*>(g.src) + (size_t)b * g.H * g.W * C, 0, g.H * g.W * C * 4, 0x00020000);
-        const unsigned voff0 = (unsigned)(((hrow * g.W + wi0) * C + kg * 4) * 4);
-        unsigned okmask = 0;
-#pragma unroll
-        for (int x = 0; x < 8; ++x) okmask |= (rowok && (unsigned)(wi0 + x) < (unsigned)g.W) ? 1u << x : 0u;
-        const unsigned pixb = (unsigned)C * 4u;
-        float* const vw = smem + kg * W_PLANE + slot * 4;            // + buf*W_VBUF + (p*2 + h)*2*W_PLANE
+        // hi pieces of the thread's 8 pixels: kind kg, row rs, pixels tj*m ..; lo pieces: kind 2 + kg.  Consecutive
+        // lanes are m = 5 pixels = 20 dwords apart: conflict-free 16-byte reads.
+        const float* const rr = smem + W_RAW_BASE + ((kg * W_RROWS + rs) * W_RPX + tj * MO) * 4;
+        float* const vw = smem + kg * W_PLANE + (active ? slot : W_NSLOT - 1) * 4;   // + buf*W_VBUF + (p*2 + h)*2*W_PLANE
 
         f32x4 rh[8], rl[8];
-#define NW_LOAD_RAW(CC)                                                                            \
+#define NW_LOAD_RAW(BUF)                                                                           \
     {                                                                                              \
-        const int co_ = (((CC) >> 1) * 32 + ((CC) & 1) * 8) * 4;                                   \
         _Pragma("unroll") for (int x = 0; x < 8; ++x) {                                            \
-            const unsigned vo_ = ((okmask >> x) & 1) ? voff0 + x * pixb : 0x80000000u;             \
-            rh[x] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, vo_, co_, 0)); \
-            rl[x] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, vo_ + 64u, co_, 0)); \
+            rh[x] = *reinterpret_cast<const f32x4*>(rr + (BUF) * W_RAW + x * 4);                   \
+            rl[x] = *reinterpret_cast<const f32x4*>(rr + (BUF) * W_RAW + x * 4 + 2 * W_RKIND);     \
         }                                                                                          \
     }
         // BT, structured (fold.py: WINO_BT): even and odd parts of rows 1..6 share their sums.  Two channels at a
@@ -297,22 +332,20 @@ __global__ void __launch_bounds__((WCW + WPW) * 64) conv_wino(const ConvArgs a) 
             __builtin_amdgcn_sched_barrier(0);                                                     \
         }                                                                                          \
     }
-        // chunk cc+1 is transformed while the consumers multiply chunk cc; iteration -1 is the prologue
+        // chunk cc+1 is transformed (from the tile wave 11 staged one iteration earlier) while the consumers multiply
+        // chunk cc; the first barrier belongs to the staging of chunk 0, iteration -1 is the first transform
         long long dbg_setup = 0, dbg_landed = 0;
         if constexpr (DBG) dbg_setup = (long long)__builtin_amdgcn_s_memtime() - dbg_entry;
-        if (wave_active) NW_LOAD_RAW(0)
-        if constexpr (DBG) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            dbg_landed = (long long)__builtin_amdgcn_s_memtime() - dbg_entry;
-        }
+        __builtin_amdgcn_s_barrier();
+        if constexpr (DBG) dbg_landed = (long long)__builtin_amdgcn_s_memtime() - dbg_entry;
         long long dbg_prod = 0, dbg_bar = 0, dbg_first = 0;
 #pragma unroll 1
         for (int cc = -1; cc < NC; ++cc) {
             long long t0 = 0, t1 = 0;
             if constexpr (DBG) t0 = (long long)__builtin_amdgcn_s_memtime();
-            if (wave_active && cc + 1 < NC) {
-                if (!(DBG && (a.wino_m >> 8 & 4) && cc >= 0)) NW_PRODUCE((cc + 1) & 1)   // (its buffer was last read during chunk cc-1)
-                if (cc + 2 < NC && !(DBG && (a.wino_m >> 8 & 1))) NW_LOAD_RAW(cc + 2)
+            if (wave_active && cc + 1 < NC && !(DBG && (a.wino_m >> 8 & 4) && cc >= 0)) {
+                NW_LOAD_RAW((cc + 1) & 1)
+                NW_PRODUCE((cc + 1) & 1)                                 // (its buffer was last read during chunk cc-1)
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             if constexpr (DBG) t1 = (long long)__builtin_amdgcn_s_memtime();
@@ -322,7 +355,7 @@ __global__ void __launch_bounds__((WCW + WPW) * 64) conv_wino(const ConvArgs a) 
                 if (cc < 0) dbg_first = t1 - t0; else { dbg_prod += t1 - t0; dbg_bar += t2 - t1; }
             }
         }
-        if constexpr (DBG) {                                            // [total, first chunk (load + transform), later chunks, barrier waits]
+        if constexpr (DBG) {                                            // [total, first chunk (transform), later chunks, barrier waits]
             if (a.dbg && lane == 0) {
                 long long* d = a.dbg + ((size_t)blockIdx.x * (WCW + WPW) + wave) * 4;
                 d[0] = (long long)__builtin_amdgcn_s_memtime() - dbg_entry; d[1] = dbg_first; d[2] = dbg_prod; d[3] = dbg_bar;
@@ -389,6 +422,7 @@ __global__ void __launch_bounds__((WCW + WPW) * 64) conv_wino(const ConvArgs a) 
     NW_LOAD_B(2, 2)
     long long dbg_setup = 0;
     if constexpr (DBG) dbg_setup = (long long)__builtin_amdgcn_s_memtime() - dbg_entry;
+    __builtin_amdgcn_s_barrier();                                       // the input tile of chunk 0 is staged
     __builtin_amdgcn_s_barrier();                                       // V of chunk 0 is in LDS
     long long dbg_t0 = 0, dbg_bar = 0, dbg_t1 = 0;
     if constexpr (DBG) dbg_t0 = (long long)__builtin_amdgcn_s_memtime();
@@ -467,16 +501,19 @@ __global__ void __launch_bounds__((WCW + WPW) * 64) conv_wino(const ConvArgs a) 
 }
 
 namespace {
-constexpr size_t kWinoLds = (size_t)(8 * 64 * W_LDM) * sizeof(float) + 64 * 6 * sizeof(int4);
-static_assert(kWinoLds >= (size_t)2 * W_VBUF * sizeof(float) && kWinoLds <= 160 * 1024, "LDS of a gfx950 CU");
+constexpr size_t kWinoLdsEpi = (size_t)(8 * 64 * W_LDM) * sizeof(float) + 64 * 6 * sizeof(int4);
+constexpr size_t kWinoLdsLoop = (size_t)(2 * W_VBUF + 2 * W_RAW) * sizeof(float);      // V and staged tiles, double-buffered
+constexpr size_t kWinoLds = kWinoLdsEpi > kWinoLdsLoop ? kWinoLdsEpi : kWinoLdsLoop;
+static_assert(kWinoLds <= 160 * 1024, "LDS of a gfx950 CU");
 
 // tile-pixel block (rows x tiles) for an Ho x ntile grid: the largest useful fraction of 64-slot blocks, subject to
 // the producers' 256 threads (2 per slot) and the slots of a plane
-void wino_block(int Ho, int ntile, int KH, int* tr, int* tj) {
+void wino_block(int Ho, int ntile, int KH, int m, int* tr, int* tj) {
     double best = -1;
     for (int r = 1; r <= 64; ++r)
         for (int t = 1; r * t <= 64; ++t) {
-            if ((r + KH - 1) * t * 2 > WPW * 64 || 64 + (KH - 1) * t > W_NSLOT) continue;
+            if ((r + KH - 1) * t * 2 > (WPW - 1) * 64 || 64 + (KH - 1) * t > W_NSLOT) continue;   // transform threads, V slots
+            if (r + KH - 1 > W_RROWS || t * m + KH - 1 > W_RPX) continue;                           // staged tile
             const int nrb = (Ho + r - 1) / r, ncb = (ntile + t - 1) / t;
             // useful fraction of the MFMA work, discounted by the rows the producers transform per output row
             const double u = (double)Ho * ntile / ((double)nrb * ncb * 64) - 0.02 * (double)(r + KH - 1) / r;
@@ -508,7 +545,7 @@ static void wino_geometry(ConvArgs& a) {
     const ConvSeg& g = a.seg[0];
     a.wino_m = 9 - g.KW;                                               // 8 positions: 5 outputs for 4 taps, 6 for 3
     a.wino_ntile = (a.Wo + a.wino_m - 1) / a.wino_m;
-    wino_block(a.Ho, a.wino_ntile, g.KH, &a.wino_tr, &a.wino_tj);
+    wino_block(a.Ho, a.wino_ntile, g.KH, a.wino_m, &a.wino_tr, &a.wino_tj);
     a.wino_nrb = (a.Ho + a.wino_tr - 1) / a.wino_tr;
     a.wino_ncb = (a.wino_ntile + a.wino_tj - 1) / a.wino_tj;
 }
