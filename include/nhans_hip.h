@@ -80,8 +80,8 @@ int nhans_create(int model_kind, const void* folded_blob, size_t nbytes, int dev
 void nhans_destroy(nhans_ctx* ctx);
 
 /* Options: "frames_per_chunk" (mask-net frame windows per pass, 1..4769 -- the conv kernels address a pass's
- *           largest tensor, frames x 35 x 201 x 64 elements, with 32-bit offsets; default 3776: 20 GB of workspace
- *           for batches that large, 5.4 MB per frame, chosen so that the launches fill whole waves of 256 workgroups),
+ *           largest tensor, frames x 35 x 201 x 64 elements, with 32-bit offsets; default 3776: 24 GB of workspace
+ *           for batches that large, 6.4 MB per frame, chosen so that the launches fill whole waves of 256 workgroups),
  *          "contexts_per_chunk" (embedding-tower images per pass, default 64),
  *          "profile" (1: time every kernel launch with hipEvents on the launch stream),
  *          "precision" (0: exact f32 matrix-core path, default; 1: split-f16 x3 -- every operand is
