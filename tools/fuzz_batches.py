@@ -36,13 +36,14 @@ def main():
             ca = normalise(synth.silent()) if kind == "denoiser" else normalise(synth.speaker_context(500 + i, low=True))
             cb = normalise(synth.noise_context(500 + i)) if kind == "denoiser" else normalise(synth.speaker_context(500 + i, low=False))
             pool.append((mix, ca, cb))
-        alone = {}                                      # (precision, conv_variant, clip) -> results with default knobs
+        alone = {}                                      # (precision, conv_variant, winograd, clip) -> results with default knobs
 
-        def reference(prec, variant, i):
-            key = (prec, variant, i)
+        def reference(prec, variant, wino, i):
+            key = (prec, variant, wino, i)
             if key not in alone:
                 eng.set_precision(prec)
                 eng.set_option("conv_variant", variant)
+                eng.set_option("winograd", wino)
                 eng.set_option("frames_per_chunk", 3776)
                 for k, v in defaults.items():
                     eng.set_option(k, v)
@@ -56,12 +57,14 @@ def main():
             ids = [int(x) for x in rng.integers(0, len(pool), n)]
             prec = "f16x3" if rng.random() < 0.8 else "f32"
             variant = int(rng.choice(variants))
-            refs = [reference(prec, variant, i) for i in ids]
+            wino = int(rng.random() < 0.7)               # Winograd form of the 4x4 stack convs (another summation: part of the key)
+            refs = [reference(prec, variant, wino, i) for i in ids]
             fpc = int(rng.choice([1, 7, 33, 100, 257, 1024, 3776]))
             cfg = {k: int(rng.integers(0, 3 if k == "consumer_interleave" else 2)) for k in knobs}
             cfg["contexts_per_chunk"] = int(rng.choice([1, 3, 5, 64]))      # tower passes with a remainder chunk
             eng.set_precision(prec)
             eng.set_option("conv_variant", variant)
+            eng.set_option("winograd", wino)
             eng.set_option("frames_per_chunk", fpc)
             for k, v in cfg.items():
                 eng.set_option(k, v)
@@ -78,7 +81,7 @@ def main():
                 if not ok:
                     bad += 1
                     fr = np.abs(got_lg - lg).max(axis=1)
-                    print("MISMATCH", kind, "iter", it, "clip", i, "pos", k, "of", ids, prec, "variant", variant, "fpc", fpc, cfg,
+                    print("MISMATCH", kind, "iter", it, "clip", i, "pos", k, "of", ids, prec, "variant", variant, "winograd", wino, "fpc", fpc, cfg,
                           "logits %.3g" % float(fr.max()), "frames differing", int((fr > 0).sum()), "of", len(fr),
                           "first", int(np.argmax(fr > 0)), "| emb %.3g" % float(np.abs(got_emb - emb).max()),
                           "| logmag %.3g" % float(np.abs(got_lm - lm).max()), "| frames before", f0 - len(lg))
