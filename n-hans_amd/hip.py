@@ -7,7 +7,9 @@ import json
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libnhans_hip.so")
+# ($NHANS_LIB: another build of the same library for a same-box A/B of two kernels -- a developer convenience of this
+# Python binding; the library itself reads no environment)
+LIB_PATH = os.environ.get("NHANS_LIB") or os.path.join(_HERE, "csrc", "libnhans_hip.so")
 
 DENOISER, SEPARATOR = 0, 1
 KIND_CODE = {"denoiser": DENOISER, "separator": SEPARATOR}
