@@ -175,7 +175,9 @@ def wino_outputs(kw):
 
 
 def wino_eligible(kh, kw, sh, sw, cin, cout):
-    return (sh, sw) == (1, 1) and kw in (3, 4) and cin % 16 == 0 and cout % 64 == 0
+    """What conv_wino.hip runs: stride-1 4x4 convs (the F(6,3) form of the 3x3 convs is not built -- their 9x51 / 5x26
+    images fill 63 % of a tile-pixel block -- so their 94 MB of packs are not emitted either)."""
+    return (sh, sw) == (1, 1) and (kh, kw) == (4, 4) and cin % 16 == 0 and cout % 64 == 0
 
 
 def pack_wino(w4):
