@@ -20,19 +20,21 @@
 // tile-pixels (TR rows x TJ tiles, <= 64; tile-pixel q = r*TJ + t):
 //   * consumer wave p owns position p: accumulators M_p[64 tile-pixels][64 channels] (2 x 2 MFMA tiles, the same
 //     wave tile as the halo kernel), its A operand V_p comes from LDS, its B operand U_p -- private to the wave,
-//     so nothing to share through LDS -- straight from L2 into registers, one k-step (16 channels of one filter
-//     row) ahead.
-//   * the producers read the (TR + KH - 1) x TJ input tiles of a 16-channel chunk from global memory into
-//     registers (8 pixels x 8 channels per thread), transform, re-split and write V into LDS in exactly the
-//     order the MFMA fragments are read: plane (p, hi|lo, k-group) holds one 16-byte piece per (row, tile) slot,
+//     so nothing to share through LDS -- straight from L2 into a register ring of one chunk (KH k-steps of 16
+//     channels), three k-steps ahead.
+//   * producer wave 11 stages the (TR + KH - 1) rows x (TJ*m + KH - 1) pixels of a 16-channel chunk in LDS by
+//     LDS-DMA (coalesced rows, every pixel once), one chunk ahead of the transform; producer waves 8-10 read their
+//     8 pixels x 8 channels per thread from there, transform, re-split and write V into LDS in exactly the order
+//     the MFMA fragments are read: plane (p, hi|lo, k-group) holds one 16-byte piece per (row, tile) slot,
 //     slot = rowslot*TJ + t, so the A fragment of filter row kh is the fragment of kh = 0 shifted by kh*TJ slots
 //     and every ds_read_b128 covers 32 consecutive pieces (conflict-free).
-//   * V is double-buffered by chunk; ONE barrier per chunk joins all twelve waves.
-//   * epilogue: the eight M_p tiles go to LDS, conv_epilogue_sweep8<WINO> combines them with AT per output column
-//     and applies the usual fused block epilogue (bias, position table, residual, ReLU, split store).
+//   * V and the staged tile are double-buffered by chunk; ONE barrier per chunk joins all twelve waves.
+//   * epilogue: the eight M_p tiles go to LDS, wino_sweep forms the m output columns of a tile-pixel from them and
+//     applies the usual fused block epilogue (bias, position table, residual, ReLU, saturation flag, split store).
 //
-// Eligibility (launcher): split-f16 mode, one segment, stride 1, SAME padding, KH in {3, 4} == KW, Cin % 16 == 0,
-// N % 64 == 0, split-NHWC input and output, 8-channel epilogue path.
+// Eligibility (launcher): split-f16 mode, one segment, stride 1, SAME padding, 4x4 filters (the ring parity of the
+// loop assumes an even KH; the 3x3 layers' images fit F(6,3) tile blocks badly and stay on the direct kernel),
+// Cin % 16 == 0, N % 64 == 0, split-NHWC input and output.
 #include "conv_epilogue.h"
 
 #include <algorithm>
@@ -49,7 +51,7 @@ constexpr int W_LDM = 68;                      // epilogue: floats per tile-pixe
 constexpr int W_RROWS = 12, W_RPX = 40;        // staged input tile of a chunk: rows (TR + KH - 1 <= 12) x pixels (TJ*m + 3 <= 40)
 constexpr int W_RKIND = W_RROWS * W_RPX * 4;   // floats per piece kind (hi|lo x k-group): one 16-byte piece per (row, pixel)
 constexpr int W_RAW = 4 * W_RKIND;             // floats per staged tile
-constexpr int W_RAW_BASE = 2 * W_VBUF;         // after the two V buffers
+constexpr int W_RAW_BASE = 2 * W_VBUF;         // the two staged tiles sit after the two V buffers
 
 // split of two f32 values into packed f16 pairs: hi = RNE(v) (one v_cvt_pk_f16_f32), lo = RNE(v - hi) as one
 // v_fma_mixlo_f16 / v_fma_mixhi_f16 each (f16 source, f32 addend, f16 result into one half of the destination)
@@ -83,8 +85,7 @@ template <int SEL> __device__ __forceinline__ float unsplit_mix(float hi_pair, f
 // transformed-domain accumulator tiles M_p[64 tile-pixels][W_LDM] (channel 8a + 4b + c of a row at float b*32 + a*4 + c:
 // the eight threads of a tile-pixel read 128 contiguous bytes at a time).  The thread reads its 8 x 8 values ONCE and
 // forms all MO output columns Y_i = sum_p AT[i][p] M_p with the shared sums of the +-1, +-2, +-1/2 point pairs
-// (18 instead of 8*MO operations per channel); local pixel i*64 + q is output column i of tile-pixel q.  The global
-// loads of every column (position table, residual) are in flight before the LDS reads start: one memory round trip.
+// (18 instead of 8*MO operations per channel); local pixel i*64 + q is output column i of tile-pixel q.
 // IDM: 0 no residual, 1 split-NHWC tensor, 2 f32 NHWC tensor, 3 one-channel image.
 template <int IDM, int MO>
 __device__ __forceinline__ void wino_sweep(const ConvArgs& a, const float* ct, const int4* rowinfo, int q, int c8, int n,
@@ -95,9 +96,9 @@ __device__ __forceinline__ void wino_sweep(const ConvArgs& a, const float* ct, c
     const float lo_clamp = a.relu ? 0.f : -3.0e38f;
     bool sat = false;
 
-    // The residual (HBM: ~2,500 cycles under load) of the first four columns is requested before the LDS reads of the
-    // output transform start, the rest four columns ahead -- two memory round trips per tile, not one per column; the position table (L2) follows
-    // one column ahead of its use.
+    // The residual (HBM: ~2,500 cycles under load) of a column is requested two columns ahead of its use -- the first
+    // two before the LDS reads of the output transform start --, the position table (L2) one column ahead; more in
+    // flight does not fit the register file (measured: the loaded values spill, with a wait in front of the spill).
     Epi8Raw<IDM> r[MO];
     auto request = [&](int i) {
         const int4 ri = rowinfo[i * 64 + q];
