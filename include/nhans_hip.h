@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define NHANS_ABI_VERSION 2
+#define NHANS_ABI_VERSION 3
 
 #define NHANS_DENOISER 0   /* SN model: emb_a = positive context (--pos), emb_b = negative (--neg) */
 #define NHANS_SEPARATOR 1  /* SS model: emb_a = interferer  (--neg),      emb_b = target   (--pos) */
@@ -57,7 +57,12 @@ extern "C" {
 /* sticky device-side status bits, see nhans_take_status() */
 #define NHANS_STATUS_SATURATED 1   /* precision 1: an activation did not fit the f16 range (|v| >= 65504 or NaN)
                                       and was clamped -- the outputs of the calls since the last
-                                      nhans_take_status() are not trustworthy; rerun them with precision 0 */
+                                      nhans_take_status() are not trustworthy; rerun them with precision 0,
+                                      best inside a "calibrate" bracket so that the exponents follow */
+
+/* tensors of the network that carry an activation exponent (see "calibrate" below): tower block b conv1 / conv2
+ * outputs at 2b / 2b+1 (b < 4), stack block b conv1 / conv2 outputs at 8+2b / 8+2b+1 (b < 8), last_conv at 24 */
+#define NHANS_NUM_ACTIVATIONS 25
 
 #define NHANS_WIN 400
 #define NHANS_HOP 160
@@ -75,7 +80,9 @@ const char* nhans_last_error(void);
 int64_t nhans_num_frames(int64_t nsamples);
 
 /* Build a context from the folded-weights blob produced by nhans_amd.fold.fold_weights()
- * (format documented in n-hans_amd/fold.py).  The blob is copied to the device. */
+ * (format documented in n-hans_amd/fold.py).  The blob is copied to the device.  If the blob carries split-f16
+ * weights, the activation exponents are calibrated here on a built-in two-second signal (one small pass of the whole
+ * path in f32 mode; see "calibrate"). */
 int nhans_create(int model_kind, const void* folded_blob, size_t nbytes, int device_id, nhans_ctx** out);
 void nhans_destroy(nhans_ctx* ctx);
 
@@ -96,6 +103,15 @@ void nhans_destroy(nhans_ctx* ctx);
  *          "consumer_interleave" (1, default: the MFMA waves of the halo kernel issue their LDS operand
  *           reads between their MFMAs, one behind each of the first MFMAs of a half-tap; 2: spread evenly over the
  *           half-tap; 0: read block then MFMA block -- identical bits, kept for A/B),
+ *          "calibrate" (activation exponents of the split-f16 mode: every stored tensor is kept as x * 2^-e with one
+ *           integer e per tensor, so that models whose activations are far from O(1) -- no BatchNorm statistics can
+ *           promise that -- stay inside the f16 range instead of tripping NHANS_STATUS_SATURATED; scaling by a power
+ *           of two is exact, the arithmetic is otherwise bit for bit that of e = 0.  1: start recording the largest
+ *           |x| of every tensor in the calls that follow (any precision; precision 0 cannot saturate and is what a
+ *           calibration on own data should use); 0: stop and set every e so that the recorded maximum is stored as
+ *           at most 2^8; 2: stop and only RAISE exponents (what a caller does after a saturated batch: rerun it at
+ *           precision 0 inside the bracket -- that is the correct result for it -- and go on at precision 1).
+ *           Stopping synchronises the device.  A maximum that is not finite is refused with NHANS_EINVAL.),
  *          "winograd" (1, default: in split-f16 mode the stride-1 4x4 convs of the residual stack run as 1-D
  *           Winograd convolutions F(5,4) along the image width, 2.5 x fewer matrix-core MACs -- conv_wino.hip;
  *           0: the direct kernels for every conv -- results agree to ~1e-5 on the logits),
@@ -113,6 +129,13 @@ void nhans_destroy(nhans_ctx* ctx);
  * Besides the workspace a context holds 64 MB of split-K scratch for the few launches that are
  * too small to fill the chip (the head's dense layer, the embedding tower at a few clips). */
 int nhans_set_option(nhans_ctx* ctx, const char* key, int64_t value);
+
+/* Activation exponents (see "calibrate"): n must be NHANS_NUM_ACTIVATIONS.  Tensors that share one accumulator -- the
+ * input of a channel-changing block and its conv1 output -- are kept on one exponent (the larger); `get` returns what
+ * is in effect.  nhans_get_activation_amax: the maxima the last finished calibration recorded. */
+int nhans_set_activation_exponents(nhans_ctx* ctx, const int* e, int n);
+int nhans_get_activation_exponents(nhans_ctx* ctx, int* e_out, int n);
+int nhans_get_activation_amax(nhans_ctx* ctx, float* amax_out, int n);
 
 /* Bytes of device workspace the context would hold for a batch of this shape. */
 size_t nhans_workspace_bytes(nhans_ctx* ctx, int64_t total_frames, int nclips);

@@ -5,8 +5,8 @@
 namespace nhans {
 
 // Clamp to the f16 range before a split (hi/lo) store; true if anything was out of range or NaN.
-__device__ __forceinline__ bool split_clamp(float4& v) {
-    const bool sat = !(fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))) < 65504.f);
+__device__ __forceinline__ bool split_clamp(float4& v, float limit) {
+    const bool sat = !(fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))) < limit);
     v.x = fminf(fmaxf(v.x, -65504.f), 65504.f); v.y = fminf(fmaxf(v.y, -65504.f), 65504.f);
     v.z = fminf(fmaxf(v.z, -65504.f), 65504.f); v.w = fminf(fmaxf(v.w, -65504.f), 65504.f);
     return sat;
@@ -55,11 +55,12 @@ __global__ void __launch_bounds__(256) direct_conv64(const DirectArgs a) {
             acc.x = fmaxf(acc.x, 0.f); acc.y = fmaxf(acc.y, 0.f);
             acc.z = fmaxf(acc.z, 0.f); acc.w = fmaxf(acc.w, 0.f);
         }
+        acc.x *= a.out_scale; acc.y *= a.out_scale; acc.z *= a.out_scale; acc.w *= a.out_scale;   // (1 for f32 outputs)
         if (a.out_split) {
             // split NHWC: group g = c/32 of pixel m is one 128-byte line, 32 hi halfs then 32 lo halfs
             typedef _Float16 h4 __attribute__((ext_vector_type(4)));
             h4 hi, lo;
-            if (split_clamp(acc) && a.sat) atomicOr(a.sat, kSatActivation);
+            if (split_clamp(acc, a.sat_limit) && a.sat) atomicOr(a.sat, kSatActivation);
             hi.x = (_Float16)acc.x; hi.y = (_Float16)acc.y; hi.z = (_Float16)acc.z; hi.w = (_Float16)acc.w;
             lo.x = (_Float16)(acc.x - (float)hi.x); lo.y = (_Float16)(acc.y - (float)hi.y);
             lo.z = (_Float16)(acc.z - (float)hi.z); lo.w = (_Float16)(acc.w - (float)hi.w);
@@ -125,10 +126,11 @@ __global__ void __launch_bounds__(256) direct_conv64_4x4(const DirectArgs a, int
                 acc.x = fmaxf(acc.x, 0.f); acc.y = fmaxf(acc.y, 0.f);
                 acc.z = fmaxf(acc.z, 0.f); acc.w = fmaxf(acc.w, 0.f);
             }
+            acc.x *= a.out_scale; acc.y *= a.out_scale; acc.z *= a.out_scale; acc.w *= a.out_scale;
             if constexpr (SPLIT) {
                 typedef _Float16 h4 __attribute__((ext_vector_type(4)));
                 h4 hi, lo;
-                if (split_clamp(acc) && a.sat) atomicOr(a.sat, kSatActivation);
+                if (split_clamp(acc, a.sat_limit) && a.sat) atomicOr(a.sat, kSatActivation);
                 hi.x = (_Float16)acc.x; hi.y = (_Float16)acc.y; hi.z = (_Float16)acc.z; hi.w = (_Float16)acc.w;
                 lo.x = (_Float16)(acc.x - (float)hi.x); lo.y = (_Float16)(acc.y - (float)hi.y);
                 lo.z = (_Float16)(acc.z - (float)hi.z); lo.w = (_Float16)(acc.w - (float)hi.w);
@@ -142,21 +144,53 @@ __global__ void __launch_bounds__(256) direct_conv64_4x4(const DirectArgs a, int
     }
 }
 
-__global__ void __launch_bounds__(256) unsplit_kernel(const float* src, int64_t total, int C, float* dst) {
+__global__ void __launch_bounds__(256) unsplit_kernel(const float* src, int64_t total, int C, float scale, float* dst) {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
         const int64_t m = i / C;
         const int n = (int)(i - m * C);
         const _Float16* p = reinterpret_cast<const _Float16*>(src + m * C) + (n >> 5) * 64 + (n & 31);
-        dst[i] = (float)p[0] + (float)p[32];
+        dst[i] = ((float)p[0] + (float)p[32]) * scale;
     }
 }
 
-void launch_unsplit(const float* src, int64_t M, int C, float* dst, hipStream_t s) {
+void launch_unsplit(const float* src, int64_t M, int C, float scale, float* dst, hipStream_t s) {
     const int64_t total = M * C;
     if (total <= 0) return;
     int64_t blocks = (total + 255) / 256;
     if (blocks > 256 * 32) blocks = 256 * 32;
-    NHANS_LAUNCH("unsplit", unsplit_kernel, dim3((unsigned)blocks), dim3(256), 0, s, src, total, C, dst);
+    NHANS_LAUNCH("unsplit", unsplit_kernel, dim3((unsigned)blocks), dim3(256), 0, s, src, total, C, scale, dst);
+}
+
+// Calibration tap (nhans_api.hip: activation exponents): running maximum of |x| * scale over a tensor.  Split tensors
+// are read as plain halfs -- the hi half of a value bounds it to 2^-11, and a lo half is never larger than its hi.
+__global__ void __launch_bounds__(256) absmax_kernel(const uint32_t* x, size_t nwords, int split, float scale, unsigned* slot) {
+    float m = 0.f;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nwords; i += (size_t)gridDim.x * 256) {
+        const uint32_t w = x[i];
+        float v;
+        if (split) {
+            typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+            const h2 h = __builtin_bit_cast(h2, w);
+            v = fmaxf(fabsf((float)h.x), fabsf((float)h.y));
+        } else {
+            v = fabsf(__builtin_bit_cast(float, w));
+        }
+        m = v > m || v != v ? v : m;                       // (a NaN sticks: the host sees it)
+    }
+    m *= scale;
+    for (int o = 32; o > 0; o >>= 1) {
+        const float t = __shfl_xor(m, o);
+        m = t > m || t != t ? t : m;
+    }
+    // non-negative floats order like their bit patterns; a NaN has the largest pattern of all
+    if ((threadIdx.x & 63) == 0) atomicMax(slot, __builtin_bit_cast(unsigned, m));
+}
+
+void launch_absmax(const float* x, size_t nwords, int split, float scale, unsigned* slot, hipStream_t s) {
+    if (nwords == 0) return;
+    size_t blocks = (nwords + 255) / 256;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    NHANS_LAUNCH("absmax", absmax_kernel, dim3((unsigned)blocks), dim3(256), 0, s, reinterpret_cast<const uint32_t*>(x), nwords, split, scale, slot);
 }
 
 void launch_direct_conv64(const DirectArgs& a, hipStream_t s) {
@@ -222,7 +256,7 @@ void launch_gather_windows(const float* logmag, const int* f_t, const int* f_T, 
 // ---------------------------------------------------------------------------------------------
 // tf.nn.avg_pool2d over the whole map (SN/main.py:199-202).  One block per (image, 64 channels);
 // fixed summation order -> deterministic.
-__global__ void __launch_bounds__(256) avgpool_kernel(const float* x, int HW, int C, int split, float* out) {
+__global__ void __launch_bounds__(256) avgpool_kernel(const float* x, int HW, int C, int split, float scale, float* out) {
     __shared__ float part[4][64];
     const int b = blockIdx.x, cg = blockIdx.y;
     const int c = cg * 64 + (threadIdx.x & 63), p = threadIdx.x >> 6;
@@ -238,13 +272,13 @@ __global__ void __launch_bounds__(256) avgpool_kernel(const float* x, int HW, in
     __syncthreads();
     if (p == 0) {
         const int l = threadIdx.x & 63;
-        out[(size_t)b * C + c] = (((part[0][l] + part[1][l]) + part[2][l]) + part[3][l]) / (float)HW;
+        out[(size_t)b * C + c] = (((part[0][l] + part[1][l]) + part[2][l]) + part[3][l]) / (float)HW * scale;
     }
 }
 
-void launch_avgpool(const float* x, int B, int HW, int C, int split, float* out, hipStream_t s) {
+void launch_avgpool(const float* x, int B, int HW, int C, int split, float scale, float* out, hipStream_t s) {
     if (B <= 0) return;
-    NHANS_LAUNCH("avgpool", avgpool_kernel, dim3(B, C / 64), dim3(256), 0, s, x, HW, C, split, out);
+    NHANS_LAUNCH("avgpool", avgpool_kernel, dim3(B, C / 64), dim3(256), 0, s, x, HW, C, split, scale, out);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -4,6 +4,8 @@
 //     aux = v                                                            (optional pre-residual tap)
 //     v  += idw[n] * residual                                            (tensor / 1-channel image)
 //     out = relu ? max(v, 0) : v      as f32 NHWC or split NHWC (hi/lo halfs)
+// Split tensors are stored times 2^-e (ConvArgs::in_scale / id_scale / out_scale): ws and idw take the input's and
+// the residual's 2^e, `out` is multiplied by the output's 2^-e after the ReLU -- exact, so v has the bits of e = 0.
 //
 // The accumulator tile goes through LDS once so that the global side is fully coalesced: the K loop
 // leaves each lane with 4 consecutive channels of ONE pixel per register quad (the weights are the
@@ -101,10 +103,11 @@ __device__ __forceinline__ void conv_epilogue_sweep(const ConvArgs& a, const flo
     const float* __restrict__ cbp = a.cb;
     const float* __restrict__ tfp = a.tf ? a.tf : a.zero;     // an absent table reads the zero page
     f32x4 wsv = {1.f, 1.f, 1.f, 1.f}, idwv = {0.f, 0.f, 0.f, 0.f};
-    if constexpr (PREC == 1) wsv = *reinterpret_cast<const f32x4*>(a.ws + n);
-    if constexpr (IDM != 0) idwv = *reinterpret_cast<const f32x4*>(a.idw + n);
+    if constexpr (PREC == 1) wsv = *reinterpret_cast<const f32x4*>(a.ws + n) * a.in_scale;
+    if constexpr (IDM != 0) idwv = *reinterpret_cast<const f32x4*>(a.idw + n) * a.id_scale;
     const int hoff = (n >> 5) * 64 + (n & 31);                // half index inside a split-NHWC pixel
     const float lo_clamp = a.relu ? 0.f : -3.0e38f;           // branch-free ReLU
+    const float osc = a.out_scale;
     bool sat = false;                                         // split output: a value that does not fit f16
 #pragma unroll 1
     for (int pg = 0; pg < PASSES; pg += GP) {
@@ -131,7 +134,7 @@ __device__ __forceinline__ void conv_epilogue_sweep(const ConvArgs& a, const flo
                 idv = f32x4{sv, sv, sv, sv};
             }
             const f32x4 y = epi_combine(av, wsv, c, t, idwv, idv);
-            yv[u] = f32x4{fmaxf(y.x, lo_clamp), fmaxf(y.y, lo_clamp), fmaxf(y.z, lo_clamp), fmaxf(y.w, lo_clamp)};
+            yv[u] = f32x4{fmaxf(y.x, lo_clamp), fmaxf(y.y, lo_clamp), fmaxf(y.z, lo_clamp), fmaxf(y.w, lo_clamp)} * osc;
         }
 #pragma unroll
         for (int u = 0; u < GP; ++u) {
@@ -142,7 +145,7 @@ __device__ __forceinline__ void conv_epilogue_sweep(const ConvArgs& a, const flo
                     f16x4 h, l;
                     float yc;
                     // (negated comparison: NaN counts as saturated too)
-                    sat |= !(fmaxf(fmaxf(fabsf(y.x), fabsf(y.y)), fmaxf(fabsf(y.z), fabsf(y.w))) < 65504.f);
+                    sat |= !(fmaxf(fmaxf(fabsf(y.x), fabsf(y.y)), fmaxf(fabsf(y.z), fabsf(y.w))) < a.sat_limit);
                     yc = fminf(fmaxf(y.x, -65504.f), 65504.f); h.x = (_Float16)yc; l.x = (_Float16)(yc - (float)h.x);
                     yc = fminf(fmaxf(y.y, -65504.f), 65504.f); h.y = (_Float16)yc; l.y = (_Float16)(yc - (float)h.y);
                     yc = fminf(fmaxf(y.z, -65504.f), 65504.f); h.z = (_Float16)yc; l.z = (_Float16)(yc - (float)h.z);
@@ -191,8 +194,15 @@ __device__ __forceinline__ void conv_epilogue_sweep8(const ConvArgs& a, const fl
     const float* __restrict__ cbp = a.cb;
     const float* __restrict__ tfp = a.tf ? a.tf : a.zero;
     f32x4 ws0 = {1.f, 1.f, 1.f, 1.f}, ws1 = ws0, iw0 = {0.f, 0.f, 0.f, 0.f}, iw1 = iw0;
-    if constexpr (PREC == 1) { ws0 = *reinterpret_cast<const f32x4*>(a.ws + n); ws1 = *reinterpret_cast<const f32x4*>(a.ws + n + 4); }
-    if constexpr (IDM != 0) { iw0 = *reinterpret_cast<const f32x4*>(a.idw + n); iw1 = *reinterpret_cast<const f32x4*>(a.idw + n + 4); }
+    if constexpr (PREC == 1) {
+        ws0 = *reinterpret_cast<const f32x4*>(a.ws + n) * a.in_scale;
+        ws1 = *reinterpret_cast<const f32x4*>(a.ws + n + 4) * a.in_scale;
+    }
+    if constexpr (IDM != 0) {
+        iw0 = *reinterpret_cast<const f32x4*>(a.idw + n) * a.id_scale;
+        iw1 = *reinterpret_cast<const f32x4*>(a.idw + n + 4) * a.id_scale;
+    }
+    const float osc = a.out_scale, slim = a.sat_limit;
     f32x4 hc0 = {0.f, 0.f, 0.f, 0.f}, hc1 = hc0;             // HOIST: the one clip's bias, loaded once
     if constexpr (HOIST) {
         const int cx = rowinfo[0].x;
@@ -247,8 +257,8 @@ __device__ __forceinline__ void conv_epilogue_sweep8(const ConvArgs& a, const fl
                 f16x8 h, l;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
-                    const float y = fmaxf(e < 4 ? r0[e] : r1[e - 4], lo_clamp);
-                    sat |= !(fabsf(y) < 65504.f);
+                    const float y = fmaxf(e < 4 ? r0[e] : r1[e - 4], lo_clamp) * osc;
+                    sat |= !(fabsf(y) < slim);
                     const float yc = fminf(fmaxf(y, -65504.f), 65504.f);
                     h[e] = (_Float16)yc;
                     l[e] = (_Float16)(yc - (float)h[e]);
@@ -373,14 +383,15 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[T
                 const int ne = n + e;
                 if (ne >= a.Nreal) continue;
                 float x = ct[p * LDC + c4 * 4 + e];
-                x = __builtin_fmaf(x, PREC == 1 ? a.ws[ne] : 1.f, cbp[ri.x + ne]) + tfp[(ri.y + ne) * f_tf];
+                x = __builtin_fmaf(x, PREC == 1 ? a.ws[ne] * a.in_scale : 1.f, cbp[ri.x + ne]) + tfp[(ri.y + ne) * f_tf];
                 float y = x;
+                const float iw = a.id_mode ? a.idw[ne] * a.id_scale : 0.f;
                 if (a.id_mode == 1)
-                    y = __builtin_fmaf(a.idw[ne], id_split ? split_load(a.id, (size_t)m * a.id_ld, ne) : a.id[(size_t)m * a.id_ld + ne], y);
-                else if (a.id_mode == 2) y = __builtin_fmaf(a.idw[ne], idsv, y);
+                    y = __builtin_fmaf(iw, id_split ? split_load(a.id, (size_t)m * a.id_ld, ne) : a.id[(size_t)m * a.id_ld + ne], y);
+                else if (a.id_mode == 2) y = __builtin_fmaf(iw, idsv, y);
                 if (a.relu) y = fmaxf(y, 0.f);
                 if (a.aux) a.aux[(size_t)m * a.aux_ld + ne] = x;
-                a.out[(size_t)m * a.ldo + ne] = y;
+                a.out[(size_t)m * a.ldo + ne] = y * a.out_scale;
             }
         }
     }

@@ -436,11 +436,11 @@ __global__ void __launch_bounds__((NCW + NPW) * 64) conv_igemm_halo_persist(cons
                 const int n = chan0(j);
                 const int hoff = (n >> 5) * 64 + (n & 31);
                 const int rl = ps * RPP + rl0;
-                const f32x4 ws0 = *reinterpret_cast<const f32x4*>(a.ws + n), ws1 = *reinterpret_cast<const f32x4*>(a.ws + n + 4);
+                const f32x4 ws0 = *reinterpret_cast<const f32x4*>(a.ws + n) * a.in_scale, ws1 = *reinterpret_cast<const f32x4*>(a.ws + n + 4) * a.in_scale;
                 const f32x4 av0 = *reinterpret_cast<const f32x4*>(ct + rl * LDR + cg * 8);
                 const f32x4 av1 = *reinterpret_cast<const f32x4*>(ct + rl * LDR + cg * 8 + 4);
                 f32x4 i0 = {0.f, 0.f, 0.f, 0.f}, i1 = i0, iw0 = i0, iw1 = i0;
-                if (idm != 0) { iw0 = *reinterpret_cast<const f32x4*>(a.idw + n); iw1 = *reinterpret_cast<const f32x4*>(a.idw + n + 4); }
+                if (idm != 0) { iw0 = *reinterpret_cast<const f32x4*>(a.idw + n) * a.id_scale; iw1 = *reinterpret_cast<const f32x4*>(a.idw + n + 4) * a.id_scale; }
                 if (idm == 1) {
                     const f16x8 h = r.h, l = r.l;
                     i0 = f32x4{(float)h[0] + (float)l[0], (float)h[1] + (float)l[1], (float)h[2] + (float)l[2], (float)h[3] + (float)l[3]};
@@ -458,8 +458,8 @@ __global__ void __launch_bounds__((NCW + NPW) * 64) conv_igemm_halo_persist(cons
                     f16x8 h, l;
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {
-                        const float y = fmaxf(e < 4 ? r0[e] : r1[e - 4], lo_clamp);
-                        sat |= !(fabsf(y) < 65504.f);
+                        const float y = fmaxf(e < 4 ? r0[e] : r1[e - 4], lo_clamp) * a.out_scale;
+                        sat |= !(fabsf(y) < a.sat_limit);
                         const float yc = fminf(fmaxf(y, -65504.f), 65504.f);
                         h[e] = (_Float16)yc;
                         l[e] = (_Float16)(yc - (float)h[e]);

@@ -143,9 +143,14 @@ __device__ __forceinline__ void wino_sweep(const ConvArgs& a, const float* ct, c
     }
     if (kDev && es) es[2] = (long long)__builtin_amdgcn_s_memtime();
     // (per-channel constants only now: they are not needed while the 8 x 8 accumulators are live)
-    const f32x4 ws0 = *reinterpret_cast<const f32x4*>(a.ws + n), ws1 = *reinterpret_cast<const f32x4*>(a.ws + n + 4);
+    // (stored tensors carry 2^-e: ConvArgs::in_scale / id_scale / out_scale)
+    const f32x4 ws0 = *reinterpret_cast<const f32x4*>(a.ws + n) * a.in_scale, ws1 = *reinterpret_cast<const f32x4*>(a.ws + n + 4) * a.in_scale;
     f32x4 iw0 = {0.f, 0.f, 0.f, 0.f}, iw1 = iw0;
-    if constexpr (IDM != 0) { iw0 = *reinterpret_cast<const f32x4*>(a.idw + n); iw1 = *reinterpret_cast<const f32x4*>(a.idw + n + 4); }
+    if constexpr (IDM != 0) {
+        iw0 = *reinterpret_cast<const f32x4*>(a.idw + n) * a.id_scale;
+        iw1 = *reinterpret_cast<const f32x4*>(a.idw + n + 4) * a.id_scale;
+    }
+    const float osc = a.out_scale, slim = a.sat_limit;
     const int cx = rowinfo[0].x;                               // one frame = one clip: one bias vector
     const f32x4 hc0 = *reinterpret_cast<const f32x4*>(a.cb + cx + n), hc1 = *reinterpret_cast<const f32x4*>(a.cb + cx + n + 4);
     auto table = [&](int i) {                                  // position table of column i (L2-resident)
@@ -177,8 +182,8 @@ __device__ __forceinline__ void wino_sweep(const ConvArgs& a, const float* ct, c
             float yc[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                const float v = fmaxf(e < 4 ? r0[e] : r1[e - 4], lo_clamp);
-                sat |= !(fabsf(v) < 65504.f);
+                const float v = fmaxf(e < 4 ? r0[e] : r1[e - 4], lo_clamp) * osc;
+                sat |= !(fabsf(v) < slim);
                 yc[e] = fminf(fmaxf(v, -65504.f), 65504.f);
             }
             uint4 hb, lb;

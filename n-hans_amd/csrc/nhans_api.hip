@@ -4,6 +4,7 @@
 #include "nhans_kernels.h"
 
 #include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <cstring>
 #include <map>
@@ -77,6 +78,12 @@ std::vector<BlockGeo> main_geometry() {        // SN/main.py:221-229
     return v;
 }
 
+constexpr int kNumAct = NHANS_NUM_ACTIVATIONS;
+constexpr int kActTargetLog2 = 8;
+constexpr int TA(int b, int j) { return 2 * b + j; }            // tower block b, conv j+1
+constexpr int SA(int b, int j) { return 8 + 2 * b + j; }        // stack block b, conv j+1
+constexpr int kActHead = 24;                                    // last_conv
+
 struct ProfEntry {
     int calls = 0;
     double flops = 0, bytes = 0, mfma = 0;      // algorithmic FLOPs / bytes; FLOPs the matrix cores executed
@@ -131,6 +138,17 @@ struct nhans_ctx {
     int wino = 1;               // ConvArgs::wino: 1-D Winograd form of the stride-1 stack convs (conv_wino.hip)
     long long* dbg = nullptr;   // NHANS_DEV builds: per-workgroup cycle stamps of the last conv launch
     int* status_dev = nullptr;  // sticky NHANS_STATUS_* bits set by kernels (nhans_take_status)
+    // Activation exponents: a split-f16 tensor is stored as x * 2^-e with one e per tensor of the network, chosen from
+    // the largest |x| a calibration pass saw so that the stored maximum is <= 2^kActTargetLog2 -- 2^8 below the f16
+    // limit (and the 1-D Winograd transform's worst-case gain of ~20 still fits).  Tensors: tower block b conv1/conv2
+    // outputs (2b, 2b+1), stack block b conv1/conv2 outputs (8+2b, 8+2b+1), last_conv output (24).  f32 tensors carry
+    // no exponent.  The flag of nhans_take_status stays as the backstop for inputs far outside the calibration.
+    int act_exp[kNumAct] = {};
+    float act_amax[kNumAct] = {};       // what the last calibration saw (diagnostics)
+    unsigned* amax_dev = nullptr;       // running maxima (float bits) while calibrating
+    bool calibrating = false;
+    float up(int i) const { return prec ? ldexpf(1.f, act_exp[i]) : 1.f; }
+    float down(int i) const { return prec ? ldexpf(1.f, -act_exp[i]) : 1.f; }
     // ordering of consecutive calls that share the workspace (see include/nhans_hip.h)
     hipEvent_t tail_ev = nullptr;
     hipStream_t last_stream = nullptr;
@@ -229,6 +247,8 @@ void fill_epilogue_defaults(nhans_ctx* c, ConvArgs& a) {
     a.idw = nullptr; a.idH = a.idW = 0; a.idsh = a.idsw = 1; a.relu = 1; a.aux = nullptr; a.aux_ld = 0;
     a.cb_stride = 0;
     a.prec = c->prec; a.out_split = c->prec; a.id_split = 0; a.ws = nullptr;
+    a.in_scale = a.id_scale = a.out_scale = 1.f;
+    a.sat_limit = kSatLimitF16;
     a.variant = c->conv_variant >= 0 ? c->conv_variant : (c->prec == 1 ? 2 : 0);
     a.dbg = kDev ? c->dbg : nullptr;
     a.epi8 = c->epi8;
@@ -265,6 +285,20 @@ void run_conv(nhans_ctx* c, const ConvArgs& a, hipStream_t s) {
     p.done(fl, 0, name, mfma);
 }
 
+// Does conv `cv` (1 | 2) of stack block b run in its Winograd form (conv_wino.hip) with the current options?  Then the
+// launch that writes its input raises the saturation flag at kSatLimitWinoInput.
+bool wino_reader(const nhans_ctx* c, int b, int cv) {
+    if (b < 0 || b > 7 || !c->wino || c->prec != 1 || (c->conv_variant >= 0 && c->conv_variant < 2)) return false;
+    const std::string n = "m" + std::to_string(b) + ".c" + std::to_string(cv) + ".wino";
+    return c->A(n) && c->A(n + ".ws");
+}
+float sat_limit_for(const nhans_ctx* c, int b, int cv) { return wino_reader(c, b, cv) ? kSatLimitWinoInput : kSatLimitF16; }
+
+// Calibration tap: the running |x| maximum of tensor `idx` (`words` values, stored in the active precision's layout).
+void tap(nhans_ctx* c, int idx, const float* buf, size_t words, hipStream_t s) {
+    if (c->calibrating) launch_absmax(buf, words, c->prec, c->up(idx), c->amax_dev + idx, s);
+}
+
 // ---- embedding tower for `n` context images already in HBM ----------------------------------
 int embed_impl(nhans_ctx* c, const float* ctx_lm, int n, float* emb_out, float* X, float* Ab, float* Y,
                hipStream_t s) {
@@ -284,7 +318,7 @@ int embed_impl(nhans_ctx* c, const float* ctx_lm, int n, float* emb_out, float* 
                 d.Ho = g.hout; d.Wo = g.wout; d.M = nc * g.hout * g.wout; d.out = a1;
                 d.cb = c->A(p + ".c1.cb"); d.cb_stride = 0; d.img_clip = nullptr; d.tf = nullptr;
                 d.relu = 1; d.fdHoWo = make_fastdiv(g.hout * g.wout); d.fdWo = make_fastdiv(g.wout);
-                d.out_split = c->prec; d.sat = c->status_dev;
+                d.out_split = c->prec; d.sat = c->status_dev; d.out_scale = c->down(TA(0, 0)); d.sat_limit = kSatLimitF16;
                 Prof pr(c, s, "direct_conv64");
                 launch_direct_conv64(d, s);
                 pr.done(2.0 * d.M * g.kh * g.kw * 64, 0);
@@ -296,9 +330,11 @@ int embed_impl(nhans_ctx* c, const float* ctx_lm, int n, float* emb_out, float* 
                 set_out_geometry(a, nc, g.hout, g.wout, g.cout, g.cout, g.cout, a1);
                 a.cb = c->A(p + ".c1.cb");
                 a.ws = c->WS(p + ".c1");
+                a.in_scale = c->up(TA(b - 1, 1)); a.out_scale = c->down(TA(b, 0));
                 a.kgroup = -1;                  // a handful of context images: grouped sum, split-K when small
                 run_conv(c, a, s);
             }
+            tap(c, TA(b, 0), a1, (size_t)nc * g.hout * g.wout * g.cout, s);
             ConvArgs a{};
             fill_epilogue_defaults(c, a);
             a.nseg = 1;
@@ -313,12 +349,15 @@ int embed_impl(nhans_ctx* c, const float* ctx_lm, int n, float* emb_out, float* 
             set_out_geometry(a, nc, g.hout, g.wout, g.cout, g.cout, g.cout, y);
             a.cb = c->A(p + ".c2.cb");
             a.ws = c->WS(p + ".c2");
+            // (the `_transform` segment reads x, whose exponent tie_exponents() keeps equal to a1's: one accumulator)
+            a.in_scale = c->up(TA(b, 0)); a.out_scale = c->down(TA(b, 1));
             run_conv(c, a, s);                  // (stride 1: halo kernel; measured faster than split-K here)
+            tap(c, TA(b, 1), y, (size_t)nc * g.hout * g.wout * g.cout, s);
             std::swap(x, y);
         }
         const BlockGeo& g = T[3];
         Prof pr(c, s, "avgpool");
-        launch_avgpool(x, nc, g.hout * g.wout, g.cout, c->prec, emb_out + (size_t)i0 * kEmb, s);
+        launch_avgpool(x, nc, g.hout * g.wout, g.cout, c->prec, c->up(TA(3, 1)), emb_out + (size_t)i0 * kEmb, s);
         pr.done(0, (double)nc * g.hout * g.wout * g.cout * 4);
     }
     return NHANS_OK;
@@ -392,6 +431,7 @@ float* run_stack_chunk(nhans_ctx* c, const float* logmag, const StackBufs& sb, i
             d.Ho = g.hout; d.Wo = g.wout; d.M = n * g.hout * g.wout; d.out = a1;
             d.cb = cb1; d.cb_stride = c->cond_cols; d.img_clip = clipmap;
             d.tf = c->A(p + ".c1.tf"); d.relu = 1; d.out_split = c->prec; d.sat = c->status_dev;
+            d.out_scale = c->down(SA(0, 0)); d.sat_limit = sat_limit_for(c, 0, 2);
             d.fdHoWo = make_fastdiv(g.hout * g.wout); d.fdWo = make_fastdiv(g.wout);
             Prof pr(c, s, "direct_conv64");
             launch_direct_conv64(d, s);
@@ -406,8 +446,11 @@ float* run_stack_chunk(nhans_ctx* c, const float* logmag, const StackBufs& sb, i
             a.tf = c->A(p + ".c1.tf");
             a.ws = c->WS(p + ".c1");
             a.wino_u = c->A(p + ".c1.wino"); a.wino_ws = c->A(p + ".c1.wino.ws");
+            a.in_scale = c->up(SA(b - 1, 1)); a.out_scale = c->down(SA(b, 0));
+            a.sat_limit = sat_limit_for(c, b, 2);
             run_conv(c, a, s);
         }
+        tap(c, SA(b, 0), a1, (size_t)n * g.hout * g.wout * g.cout, s);
         ConvArgs a{};
         fill_epilogue_defaults(c, a);
         a.nseg = 1;
@@ -417,12 +460,15 @@ float* run_stack_chunk(nhans_ctx* c, const float* logmag, const StackBufs& sb, i
         a.idw = c->A(p + ".c2.idw");
         a.ws = c->WS(p + ".c2");
         a.wino_u = c->A(p + ".c2.wino"); a.wino_ws = c->A(p + ".c2.wino.ws");
+        a.in_scale = c->up(SA(b, 0)); a.out_scale = c->down(SA(b, 1));
+        a.sat_limit = sat_limit_for(c, b + 1, 1);
         float* out;
         if (b == 0) {                       // 1 -> 64 transform on the window image itself
             a.id_mode = 2; a.id = sb.xw; a.idH = g.hin; a.idW = g.win; a.idsh = 1; a.idsw = 1;
             out = x;
         } else if (g.cin == g.cout) {       // identity shortcut, written in place over the block input
             a.id_mode = 1; a.id = x; a.id_ld = g.cout; a.id_split = c->prec;
+            a.id_scale = c->up(SA(b - 1, 1));
             out = x;
         } else if (c->wino && c->prec == 1 && g.kh == 4 && a.variant >= 2 && a.wino_u && a.wino_ws) {
             // Channel-changing block whose conv2 has a Winograd form: the 1x1 strided `_transform` conv cannot ride in
@@ -436,17 +482,19 @@ float* run_stack_chunk(nhans_ctx* c, const float* logmag, const StackBufs& sb, i
             t.cb = c->A("zero"); t.cb_stride = 0;
             t.ws = c->WS(p + ".c2");            // (conv2 and the transform share one column scale: fold.py emit())
             t.relu = 0; t.out_split = 0;
+            t.in_scale = c->up(SA(b - 1, 1));   // (f32 output: no exponent)
             run_conv(c, t, s);
             a.id_mode = 1; a.id = sb.T; a.id_ld = g.cout; a.id_split = 0;
             a.idw = c->A("head.dense.idw");     // ones
             out = y;
-        } else {                            // 1x1 strided transform as extra K columns
+        } else {                            // 1x1 strided transform as extra K columns (x and a1 share one exponent)
             a.nseg = 2;
             a.seg[1] = make_seg(x, c->WP(p + ".c2.wpk_t"), g.hin, g.win, g.cin, 1, 1, g.sh, g.sw, false);
             out = y;
         }
         set_out_geometry(a, n, g.hout, g.wout, g.cout, g.cout, g.cout, out);
         run_conv(c, a, s);
+        tap(c, SA(b, 1), out, (size_t)n * g.hout * g.wout * g.cout, s);
         if (out == y) std::swap(x, y);
     }
     if (upto >= 9) {                        // last_conv [5,1] VALID + BN + ReLU  (SN/main.py:232-236)
@@ -458,7 +506,9 @@ float* run_stack_chunk(nhans_ctx* c, const float* logmag, const StackBufs& sb, i
         set_out_geometry(a, n, 1, g.wout, 512, 512, 512, a1);
         a.cb = c->A("head.conv.cb");
         a.ws = c->WS("head.conv");
+        a.in_scale = c->up(SA(7, 1)); a.out_scale = c->down(kActHead);
         run_conv(c, a, s);
+        tap(c, kActHead, a1, (size_t)n * g.wout * 512, s);
         return a1;
     }
     return x;
@@ -489,6 +539,7 @@ int mask_net_impl(nhans_ctx* c, const float* logmag, const int64_t* foff, int nc
         a.ws = c->WS("head.dense");
         a.out_split = 0;
         a.relu = 0;
+        a.in_scale = c->up(kActHead);
         a.id_mode = 1; a.id = logmag + g0 * kBins; a.id_ld = kBins; a.idw = c->A("head.dense.idw");
         if (logits) { a.aux = logits + g0 * kBins; a.aux_ld = kBins; }
         a.kgroup = -1;                          // K = 13312 over a few hundred frames: grouped sum, split-K when small
@@ -574,6 +625,37 @@ size_t istft_blocks(const int64_t* foff, int nclips) {
     return nb;
 }
 
+// Two tensors that feed ONE accumulator (a channel-changing block's conv2 reads its conv1 output and, through the
+// `_transform` segment, the block input) must carry one exponent: the larger of the two.
+void tie_exponents(nhans_ctx* c) {
+    auto tie = [&](int i, int j) { c->act_exp[i] = c->act_exp[j] = std::max(c->act_exp[i], c->act_exp[j]); };
+    for (int b = 1; b < 4; ++b) tie(TA(b - 1, 1), TA(b, 0));
+    for (int b = 1; b < 8; ++b)
+        if (c->stack[b].cin != c->stack[b].cout) tie(SA(b - 1, 1), SA(b, 0));
+}
+
+// End of a calibration bracket: maxima -> exponents (merge: only raise).
+int finish_calibration(nhans_ctx* c, bool merge) {
+    c->calibrating = false;
+    unsigned bits[kNumAct];
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(bits, c->amax_dev, sizeof bits, hipMemcpyDeviceToHost));
+    int e_new[kNumAct];
+    for (int i = 0; i < kNumAct; ++i) {
+        float m;
+        std::memcpy(&m, &bits[i], 4);
+        if (!std::isfinite(m))
+            return fail(NHANS_EINVAL, "calibration: tensor " + std::to_string(i) + " reached a non-finite value");
+        c->act_amax[i] = m;
+        int k = 0;
+        if (m > 0.f) (void)frexpf(m, &k);               // m = f * 2^k, f in [0.5, 1)  =>  m * 2^-(k - T) <= 2^T
+        e_new[i] = m > 0.f ? k - kActTargetLog2 : (merge ? c->act_exp[i] : 0);   // (a tensor the pass never wrote)
+    }
+    for (int i = 0; i < kNumAct; ++i) c->act_exp[i] = merge ? std::max(c->act_exp[i], e_new[i]) : e_new[i];
+    tie_exponents(c);
+    return NHANS_OK;
+}
+
 int check_ctx(nhans_ctx* c) {
     if (!c) return fail(NHANS_EINVAL, "null context");
     hipError_t e = hipSetDevice(c->device);
@@ -637,6 +719,63 @@ const char* nhans_last_error(void) { return g_err.c_str(); }
 
 int64_t nhans_num_frames(int64_t n) { return n < kWin ? 0 : 1 + (n - kWin) / kHop; }
 
+static int enhance_clips_body(nhans_ctx* c, const float* mix, const int64_t* moff, int nclips, const float* ca,
+                              const int64_t* caoff, const float* cbw, const int64_t* cboff, float* den_wav,
+                              float* mixed_wav, float* logmag_out, float* phase_out, float* logits_out, float* emb_out,
+                              void* stream);
+
+// Activation exponents of a fresh context: one pass of the whole path at precision 0 over a built-in batch of two clips
+// -- a two-second mixture of a gliding harmonic voice with syllabic amplitude modulation and noise, conditioned once on
+// two noise recordings and once on (silence, noise): an all-zero recording is the reference's default `--pos` and
+// drives the tower with the constant silence floor -- with every tensor's maximum recorded.  Deterministic (LCG).
+static int calibrate_builtin(nhans_ctx* c) {
+    const int64_t n_mix = kWin + (int64_t)kHop * 197, n_ctx = kWin + (int64_t)kHop * (kCtxFrames - 1);
+    std::vector<float> mix(2 * n_mix), ca(2 * n_ctx), cb(2 * n_ctx);
+    uint32_t lcg = 0x2545F491u;
+    auto noise = [&]() { lcg = lcg * 1664525u + 1013904223u; return (float)(int32_t)lcg * (1.0f / 2147483648.0f); };
+    double ph = 0.0;
+    for (int64_t i = 0; i < n_mix; ++i) {
+        const double t = (double)i / 16000.0;
+        ph += 2.0 * M_PI * (110.0 + 35.0 * t) / 16000.0;
+        double v = 0.0;
+        for (int h = 1; h <= 12; ++h) v += std::sin(h * ph) / h;
+        const double am = 0.5 - 0.5 * std::cos(2.0 * M_PI * 4.0 * t);
+        mix[i] = (float)(0.22 * am * v) + 0.05f * noise();
+        mix[n_mix + i] = 0.35f * mix[i] + 0.12f * noise();
+    }
+    float lp = 0.f;
+    for (int64_t i = 0; i < n_ctx; ++i) {
+        lp = 0.9f * lp + 0.1f * noise();
+        ca[i] = 0.6f * lp;                    // clip 0: low-passed noise / white noise
+        cb[i] = 0.1f * noise();
+        ca[n_ctx + i] = 0.f;                  // clip 1: silence / white noise
+        cb[n_ctx + i] = 0.25f * noise();
+    }
+    const int64_t moff[3] = {0, n_mix, 2 * n_mix}, coff[3] = {0, n_ctx, 2 * n_ctx};
+    float* dev = nullptr;
+    const size_t words = (size_t)4 * n_mix + (size_t)4 * n_ctx;
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&dev), words * 4));
+    float *d_mix = dev, *d_den = dev + 2 * n_mix, *d_ca = dev + 4 * n_mix, *d_cb = d_ca + 2 * n_ctx;
+    hipError_t e = hipMemcpy(d_mix, mix.data(), mix.size() * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d_ca, ca.data(), ca.size() * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d_cb, cb.data(), cb.size() * 4, hipMemcpyHostToDevice);
+    int rc = e == hipSuccess ? NHANS_OK : fail(NHANS_EHIP, std::string("calibration upload: ") + hipGetErrorString(e));
+    if (!rc) {
+        const int prec = c->prec;
+        c->prec = 0;
+        c->calibrating = true;
+        (void)take_launch_error(nullptr);
+        rc = enhance_clips_body(c, d_mix, moff, 2, d_ca, coff, d_cb, coff, d_den, nullptr, nullptr, nullptr, nullptr,
+                                nullptr, nullptr);
+        if (!rc) rc = launch_status();
+        const int frc = finish_calibration(c, false);       // (synchronises)
+        if (!rc) rc = frc;
+        c->prec = prec;
+    }
+    (void)hipFree(dev);
+    return rc;
+}
+
 int nhans_create(int model_kind, const void* blob, size_t nbytes, int device_id, nhans_ctx** out) {
     if (!out || !blob) return fail(NHANS_EINVAL, "null argument");
     *out = nullptr;
@@ -665,6 +804,8 @@ int nhans_create(int model_kind, const void* blob, size_t nbytes, int device_id,
     if (e != hipSuccess) { nhans_destroy(c); return fail(NHANS_ENOMEM, "split-K scratch allocation failed"); }
     e = hipMalloc(reinterpret_cast<void**>(&c->status_dev), sizeof(int));
     if (e == hipSuccess) e = hipMemset(c->status_dev, 0, sizeof(int));
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&c->amax_dev), kNumAct * sizeof(unsigned));
+    if (e == hipSuccess) e = hipMemset(c->amax_dev, 0, kNumAct * sizeof(unsigned));
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->tail_ev, hipEventDisableTiming);
     if (e != hipSuccess) { nhans_destroy(c); return fail(NHANS_EHIP, "status word / ordering event creation failed"); }
     const BlobEntry* ent = reinterpret_cast<const BlobEntry*>(static_cast<const char*>(blob) + sizeof(BlobHeader));
@@ -717,6 +858,10 @@ int nhans_create(int model_kind, const void* blob, size_t nbytes, int device_id,
             return fail(NHANS_EINVAL, msg);
         }
     }
+    if (c->A("head.dense.wpk_h")) {
+        const int rc = calibrate_builtin(c);
+        if (rc) { nhans_destroy(c); return rc; }
+    }
     *out = c;
     return NHANS_OK;
 }
@@ -730,6 +875,7 @@ void nhans_destroy(nhans_ctx* c) {
     for (hipEvent_t ev : c->event_pool) (void)hipEventDestroy(ev);
     if (c->tail_ev) (void)hipEventDestroy(c->tail_ev);
     if (c->status_dev) (void)hipFree(c->status_dev);
+    if (c->amax_dev) (void)hipFree(c->amax_dev);
     if (c->ws) (void)hipFree(c->ws);
     if (c->kscratch) (void)hipFree(c->kscratch);
     if (c->kcounter) (void)hipFree(c->kcounter);
@@ -769,6 +915,18 @@ int nhans_set_option(nhans_ctx* c, const char* key, int64_t value) {
         if (!kAB && value == 3) return fail(NHANS_EINVAL, "conv_variant 3 exists only in a `make AB=1` build of the library");
         c->conv_variant = (int)value;
     }
+    else if (k == "calibrate") {
+        if (value < 0 || value > 2) return fail(NHANS_EINVAL, "calibrate must be 1 (start), 0 (stop, set) or 2 (stop, raise only)");
+        int rc = check_ctx(c); if (rc) return rc;
+        if (value == 1) {
+            HIP_TRY(hipDeviceSynchronize());
+            HIP_TRY(hipMemset(c->amax_dev, 0, kNumAct * sizeof(unsigned)));
+            c->calibrating = true;
+        } else {
+            if (!c->calibrating) return fail(NHANS_EINVAL, "calibrate: no bracket is open");
+            return finish_calibration(c, value == 2);
+        }
+    }
     else if (k == "winograd") c->wino = value != 0;
     else if (k == "ab_build") return kAB ? NHANS_OK : fail(NHANS_EINVAL, "not an AB=1 build");   // query: 0 = yes
     else if (k == "precision") {
@@ -778,6 +936,27 @@ int nhans_set_option(nhans_ctx* c, const char* key, int64_t value) {
         c->prec = (int)value;
     }
     else return fail(NHANS_EINVAL, "unknown option " + k);
+    return NHANS_OK;
+}
+
+int nhans_set_activation_exponents(nhans_ctx* c, const int* e, int n) {
+    if (!c || !e || n != kNumAct) return fail(NHANS_EINVAL, "activation exponents: need NHANS_NUM_ACTIVATIONS values");
+    for (int i = 0; i < n; ++i)
+        if (e[i] < -60 || e[i] > 60) return fail(NHANS_EINVAL, "activation exponent outside [-60, 60]");
+    std::copy(e, e + n, c->act_exp);
+    tie_exponents(c);
+    return NHANS_OK;
+}
+
+int nhans_get_activation_exponents(nhans_ctx* c, int* e_out, int n) {
+    if (!c || !e_out || n != kNumAct) return fail(NHANS_EINVAL, "activation exponents: need NHANS_NUM_ACTIVATIONS values");
+    std::copy(c->act_exp, c->act_exp + n, e_out);
+    return NHANS_OK;
+}
+
+int nhans_get_activation_amax(nhans_ctx* c, float* amax_out, int n) {
+    if (!c || !amax_out || n != kNumAct) return fail(NHANS_EINVAL, "activation maxima: need NHANS_NUM_ACTIVATIONS values");
+    std::copy(c->act_amax, c->act_amax + n, amax_out);
     return NHANS_OK;
 }
 
@@ -866,7 +1045,7 @@ static int debug_block_output_body(nhans_ctx* c, const float* logmag, const int6
     if (block == 8) per = (size_t)26 * 512;
     else per = (size_t)c->stack[block].hout * c->stack[block].wout * c->stack[block].cout;
     if (c->prec) launch_unsplit(res, (int64_t)nframes * (int64_t)(per / (block == 8 ? 512 : c->stack[block].cout)),
-                                block == 8 ? 512 : c->stack[block].cout, out, s);
+                                block == 8 ? 512 : c->stack[block].cout, c->up(block == 8 ? kActHead : SA(block, 1)), out, s);
     else HIP_TRY(hipMemcpyAsync(out, res, per * nframes * 4, hipMemcpyDeviceToDevice, s));
     return NHANS_OK;
 }

@@ -52,6 +52,10 @@ hipError_t take_launch_error(const char** kernel);
 
 // bit set in *sat by the split-f16 writers when an activation does not fit f16 (|v| >= 65504 or NaN)
 constexpr int kSatActivation = 1;
+// conv_wino.hip re-splits V = BT d into f16: for the non-negative (post-ReLU) tensors it reads, |V| <= 8.5 max d -- the
+// largest one-signed coefficient sum of a BT row of F(5,4) -- and the f16 conversion saturates SILENTLY, so the launch
+// that writes such a tensor raises the flag at 65504 / 8.5 = 7,706 already (7,168 leaves room for the f32 rounding).
+constexpr float kSatLimitF16 = 65504.f, kSatLimitWinoInput = 7168.f;
 
 // Division by a runtime constant for numerators < 2^31 (Granlund-Montgomery round-up form).
 struct FastDiv {
@@ -114,6 +118,14 @@ struct ConvArgs {
     int out_split;         // write `out` as split NHWC (ldo = N words per pixel) instead of f32
     int id_split;          // id_mode 1 tensor is split NHWC
     const float* ws;       // prec 1: per-channel power-of-two that undoes the weight pre-scaling
+    // Split-f16 tensors are STORED times a per-tensor power of two 2^-e (nhans_api.hip: activation exponents), so that
+    // what a trained or an odd model produces stays inside the f16 range.  The epilogue computes in the unscaled
+    // domain, bit for bit what it computes with e = 0: ws is multiplied by in_scale = 2^e(input), idw by id_scale =
+    // 2^e(residual), and the result by out_scale = 2^-e(output) on its way to memory.  All three are 1 for f32 tensors.
+    float in_scale, id_scale, out_scale;
+    // the flag is raised by a stored |value| >= sat_limit: 65504 (the f16 range), or kSatLimitWinoInput for a tensor the
+    // next launch reads in its Winograd form
+    float sat_limit;
     int* sat;              // prec 1: device flag word, kSatActivation is OR-ed in when a stored activation saturates
     int variant;           // 0: 128-pixel / 4-wave register-staged kernel, 1: 256-pixel / 8-wave LDS-DMA kernel,
                            // 2, 3: LDS-DMA kernel with halo reuse across the KW taps where the conv allows it
@@ -186,12 +198,17 @@ struct DirectArgs {     // convolution of a 1-channel image into 64 channels, sa
     const float* tf;    // [Ho*Wo,64] nullable
     int relu;
     int out_split;      // write split NHWC (hi/lo f16) instead of f32
+    float out_scale;    // as ConvArgs::out_scale
+    float sat_limit;    // as ConvArgs::sat_limit
     int* sat;           // as ConvArgs::sat
     FastDiv fdHoWo, fdWo;
 };
 void launch_direct_conv64(const DirectArgs& a, hipStream_t s);
-// split NHWC [M, C] -> f32 [M, C]
-void launch_unsplit(const float* src, int64_t M, int C, float* dst, hipStream_t s);
+// split NHWC [M, C] -> f32 [M, C], times `scale`
+void launch_unsplit(const float* src, int64_t M, int C, float scale, float* dst, hipStream_t s);
+// *slot = max(*slot, scale * max|x|) over a tensor of `nwords` 32-bit words (f32 values, or pairs of f16 halfs of a
+// split-NHWC tensor: the hi halfs dominate); *slot holds the bits of a non-negative float.  Calibration only.
+void launch_absmax(const float* x, size_t nwords, int split, float scale, unsigned* slot, hipStream_t s);
 
 // frame index: for global frame g -> clip, t within clip, T of clip
 void launch_frame_index(const int64_t* frame_offsets_dev, int nclips, int64_t total, int* f_clip,
@@ -199,8 +216,8 @@ void launch_frame_index(const int64_t* frame_offsets_dev, int nclips, int64_t to
 // xw[i, h, w] = logmag row (g0+i) - t + (t+h-17) or 0.0 outside the clip   (SN/apply.py:170-186)
 void launch_gather_windows(const float* logmag, const int* f_t, const int* f_T, int64_t g0, int n,
                            float* xw, hipStream_t s);
-// mean over HW positions: x [B, HW, C] -> out [B, C]
-void launch_avgpool(const float* x, int B, int HW, int C, int split, float* out, hipStream_t s);
+// mean over HW positions, times `scale`: x [B, HW, C] -> out [B, C]
+void launch_avgpool(const float* x, int B, int HW, int C, int split, float scale, float* out, hipStream_t s);
 // cb[clip, n] = base[n] + sum_k ea[clip,k]*Wc[k, n] + sum_k eb[clip,k]*Wc[512+k, n]
 void launch_cond(const float* ea, const float* eb, int nclips, const float* Wc, const float* base,
                  int ncols, float* cb, hipStream_t s);

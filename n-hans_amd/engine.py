@@ -66,6 +66,38 @@ class Engine:
     def set_option(self, key, value):
         hip.check(self.lib.nhans_set_option(self.handle, key.encode(), int(value)))
 
+    # ---- activation exponents of the f16x3 mode (include/nhans_hip.h: "calibrate") ----------
+    def activation_exponents(self):
+        e = (ctypes.c_int * hip.NUM_ACTIVATIONS)()
+        hip.check(self.lib.nhans_get_activation_exponents(self.handle, e, hip.NUM_ACTIVATIONS))
+        return list(e)
+
+    def set_activation_exponents(self, exps):
+        e = (ctypes.c_int * hip.NUM_ACTIVATIONS)(*[int(v) for v in exps])
+        hip.check(self.lib.nhans_set_activation_exponents(self.handle, e, hip.NUM_ACTIVATIONS))
+
+    def activation_amax(self):
+        """Largest |x| of every exponent-carrying tensor in the last finished calibration."""
+        a = (ctypes.c_float * hip.NUM_ACTIVATIONS)()
+        hip.check(self.lib.nhans_get_activation_amax(self.handle, a, hip.NUM_ACTIVATIONS))
+        return list(a)
+
+    def calibrate(self, mixes, ctx_a, ctx_b, raise_only=False):
+        """Sets the activation exponents from the caller's own clips (nhans_create has calibrated on a built-in
+        signal): one f32-mode pass with every tensor's maximum recorded."""
+        before = self.precision
+        self.set_option("calibrate", 1)
+        self.set_precision("f32")
+        try:
+            mix_t, mix_off = self._dev(mixes)
+            ca_t, ca_off = self._dev(ctx_a)
+            cb_t, cb_off = self._dev(ctx_b)
+            self.enhance_device(mix_t, mix_off, ca_t, ca_off, cb_t, cb_off)
+        finally:
+            self.set_precision(before)
+            self.set_option("calibrate", 2 if raise_only else 0)
+        return self.activation_exponents()
+
     def take_status(self):
         """Waits for the current stream; returns and clears the sticky device status bits
         (hip.STATUS_SATURATED: a split-f16 activation left the f16 range and was clamped)."""
@@ -155,15 +187,19 @@ class Engine:
         cb_t, cb_off = self._dev(ctx_b)
         res = self.enhance_device(mix_t, mix_off, ca_t, ca_off, cb_t, cb_off, want_mixed, taps)
         if self.take_status() & hip.STATUS_SATURATED and self.precision == "f16x3":
-            # the split-f16 layout holds |activation| < 65504; these weights/inputs exceed it somewhere:
-            # redo the batch on the exact f32 matrix-core path (same library, no CPU involved)
-            warnings.warn("N-HANS f16x3 path: an activation left the f16 range; batch recomputed in f32 MFMA mode")
+            # the split-f16 layout holds |activation * 2^-e| < 65504 and this batch is further from the calibration
+            # than the 2^8 of headroom: redo it on the exact f32 matrix-core path (same library, no CPU involved)
+            # with the tensors' maxima recorded, and raise the exponents so that the batches after it fit
+            warnings.warn("N-HANS f16x3 path: an activation left the f16 range; batch recomputed in f32 MFMA mode "
+                          "and the activation exponents raised")
+            self.set_option("calibrate", 1)
             self.set_precision("f32")
             try:
                 res = self.enhance_device(mix_t, mix_off, ca_t, ca_off, cb_t, cb_off, want_mixed, taps)
                 self.take_status()
             finally:
                 self.set_precision("f16x3")
+                self.set_option("calibrate", 2)
         torch.cuda.synchronize(self.device)
         out = {"denoised_wav": [], "mixed_wav": []}
         den = res["denoised_wav"].cpu().numpy()

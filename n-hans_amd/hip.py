@@ -19,9 +19,12 @@ EXPORTS = [
     "nhans_set_option", "nhans_workspace_bytes", "nhans_stft_features", "nhans_embed",
     "nhans_mask_net", "nhans_istft", "nhans_enhance_clips", "nhans_debug_block_output",
     "nhans_profile_json", "nhans_profile_reset", "nhans_take_status", "nhans_debug_launch_probe", "nhans_crc32c",
-    "nhans_debug_mfma_ceiling",
+    "nhans_debug_mfma_ceiling", "nhans_set_activation_exponents", "nhans_get_activation_exponents",
+    "nhans_get_activation_amax",
 ]
 STATUS_SATURATED = 1
+NUM_ACTIVATIONS = 25
+ABI_VERSION = 3
 
 _lib = None
 
@@ -65,13 +68,17 @@ def load():
     lib.nhans_debug_mfma_ceiling.argtypes = [ctypes.c_double, vp, ctypes.POINTER(ctypes.c_double),
                                              ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int)]
     lib.nhans_debug_mfma_ceiling.restype = ctypes.c_int
+    lib.nhans_set_activation_exponents.argtypes = [vp, ctypes.POINTER(ctypes.c_int), ctypes.c_int]
+    lib.nhans_get_activation_exponents.argtypes = [vp, ctypes.POINTER(ctypes.c_int), ctypes.c_int]
+    lib.nhans_get_activation_amax.argtypes = [vp, ctypes.POINTER(ctypes.c_float), ctypes.c_int]
     lib.nhans_crc32c.argtypes = [ctypes.c_uint32, vp, ctypes.c_size_t]
     lib.nhans_crc32c.restype = ctypes.c_uint32
     for name in ("nhans_create", "nhans_set_option", "nhans_stft_features", "nhans_embed", "nhans_mask_net",
                  "nhans_istft", "nhans_enhance_clips", "nhans_debug_block_output", "nhans_profile_json",
-                 "nhans_profile_reset", "nhans_take_status", "nhans_debug_launch_probe"):
+                 "nhans_profile_reset", "nhans_take_status", "nhans_debug_launch_probe",
+                 "nhans_set_activation_exponents", "nhans_get_activation_exponents", "nhans_get_activation_amax"):
         getattr(lib, name).restype = ctypes.c_int
-    if lib.nhans_abi_version() != 2:
+    if lib.nhans_abi_version() != ABI_VERSION:
         raise NhansError("libnhans_hip.so ABI version mismatch")
     _lib = lib
     return lib

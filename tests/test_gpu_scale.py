@@ -5,6 +5,7 @@ at several batch positions, bitwise equality with the single-clip run (batch, ch
 invariance), finiteness of every output, and the STFT->iSTFT identity on sampled clips.
 """
 import os
+import warnings
 
 import numpy as np
 import pytest
@@ -316,18 +317,46 @@ def test_launch_failure_reaches_the_caller(lib_built):
     torch.cuda.synchronize()
 
 
-def test_saturation_is_detected_and_rerun_in_f32(lib_built, weights_denoiser):
-    """f16x3 carries activations as hi+lo f16: |v| >= 65504 cannot be represented.  Weights scaled so
-    that block 1 overflows must raise the status flag, and Engine.enhance must hand back the f32
-    matrix-core result instead of clamped values."""
+def _scaled_block1(weights_denoiser):
     W = dict(weights_denoiser)
     W["resblock1_1_conv1/w"] = (W["resblock1_1_conv1/w"] * np.float32(3.0e5)).astype(np.float32)
+    return W
+
+
+def test_activation_exponents_keep_out_of_range_weights_in_f16x3(lib_built, weights_denoiser):
+    """f16x3 carries activations as hi+lo f16: |stored| >= 65504 cannot be represented.  Every stored tensor has a
+    power-of-two exponent that nhans_create calibrates (include/nhans_hip.h: "calibrate"): weights scaled so that
+    block 1 would overflow by a factor of ~100 run in f16x3 WITHOUT the status flag and without an f32 rerun, and
+    agree with the f32 matrix-core result like any other model."""
+    W = _scaled_block1(weights_denoiser)
     mix, ca, cb = _clip(7, 0.3)
     e32 = engine.Engine("denoiser", W, precision="f32")
     ref = e32.enhance([mix], [ca], [cb], want_mixed=False, taps=True)
     assert e32.take_status() == 0
     e32.close()
     e16 = engine.Engine("denoiser", W, precision="f16x3")
+    exps = e16.activation_exponents()
+    assert len(exps) == hip.NUM_ACTIVATIONS and exps[8] >= 10              # stack block 0 conv1 output: ~3e5 x O(10)
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")                                       # the rerun path warns: it must not run
+        got = e16.enhance([mix], [ca], [cb], want_mixed=False, taps=True)
+    assert e16.take_status() == 0 and e16.precision == "f16x3"
+    scale = max(1.0, float(np.abs(ref["logits"]).max()))
+    assert np.abs(got["logits"] - ref["logits"]).max() <= 3e-5 * scale
+    e16.close()
+
+
+def test_saturation_is_detected_rerun_in_f32_and_the_exponents_follow(lib_built, weights_denoiser):
+    """The backstop: with the exponents forced to zero the same weights must raise the status flag; Engine.enhance
+    hands back the f32 matrix-core result of that batch instead of clamped values, raises the exponents from what the
+    rerun saw, and the next batch runs in f16x3 again without the flag."""
+    W = _scaled_block1(weights_denoiser)
+    mix, ca, cb = _clip(7, 0.3)
+    e32 = engine.Engine("denoiser", W, precision="f32")
+    ref = e32.enhance([mix], [ca], [cb], want_mixed=False, taps=True)
+    e32.close()
+    e16 = engine.Engine("denoiser", W, precision="f16x3")
+    e16.set_activation_exponents([0] * hip.NUM_ACTIVATIONS)
     mix_t, mix_off = e16._dev([mix]); ca_t, ca_off = e16._dev([ca]); cb_t, cb_off = e16._dev([cb])
     e16.enhance_device(mix_t, mix_off, ca_t, ca_off, cb_t, cb_off)
     assert e16.take_status() & hip.STATUS_SATURATED
@@ -336,7 +365,74 @@ def test_saturation_is_detected_and_rerun_in_f32(lib_built, weights_denoiser):
         got = e16.enhance([mix], [ca], [cb], want_mixed=False, taps=True)
     assert e16.precision == "f16x3"
     assert np.array_equal(got["logits"], ref["logits"])
+    assert max(e16.activation_exponents()) >= 10
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        again = e16.enhance([mix], [ca], [cb], want_mixed=False, taps=True)
+    assert e16.take_status() == 0
+    scale = max(1.0, float(np.abs(ref["logits"]).max()))
+    assert np.abs(again["logits"] - ref["logits"]).max() <= 3e-5 * scale
     e16.close()
+
+
+def test_activation_exponents_stay_inside_the_f16x3_error_envelope(eng, lib_built, weights_denoiser):
+    """Scaling a stored tensor by a power of two is exact for every value whose lo half is a normal f16; it only moves
+    the threshold below which lo turns subnormal (absolute error 2^-25 of the STORED value, the same order as the
+    2^-22 relative error of the normal range -- so the logits move by a few 1e-6, the noise floor of the format).
+    With the calibrated exponents, with all of them zero (round 2's storage), shifted by +3 and after a user
+    calibration on the clip itself the logits stay within 2e-5 of each other and within 5e-5 of the f32 matrix-core
+    path (which is itself the noisier of the two against float64: tools/exponent_accuracy.py); the exponents of
+    tensors that share an accumulator stay tied."""
+    mix, ca, cb = _clip(11, 0.25)
+    e32 = engine.Engine("denoiser", weights_denoiser, precision="f32")
+    exact = e32.enhance([mix], [ca], [cb], want_mixed=False, taps=True)["logits"]
+    e32.close()
+    base = eng.activation_exponents()
+    try:
+        ref = eng.enhance([mix], [ca], [cb], want_mixed=False, taps=True)["logits"]
+        assert eng.take_status() == 0
+        assert np.abs(ref - exact).max() <= 5e-5
+        assert np.array_equal(ref, eng.enhance([mix], [ca], [cb], want_mixed=False, taps=True)["logits"])
+        for exps in ([0] * hip.NUM_ACTIVATIONS, [e + 3 for e in base]):
+            eng.set_activation_exponents(exps)
+            got = eng.enhance([mix], [ca], [cb], want_mixed=False, taps=True)["logits"]
+            assert eng.take_status() == 0
+            assert np.abs(got - ref).max() <= 2e-5 and np.abs(got - exact).max() <= 5e-5
+        own = eng.calibrate([mix], [ca], [cb])
+        amax = eng.activation_amax()
+        assert all(0 < a * 2.0 ** -e <= 256.0 for a, e in zip(amax, own))
+        got = eng.enhance([mix], [ca], [cb], want_mixed=False, taps=True)["logits"]
+        assert np.abs(got - ref).max() <= 2e-5 and np.abs(got - exact).max() <= 5e-5
+        odd = list(base)
+        odd[1] += 5                                                            # tower block 0 output ...
+        eng.set_activation_exponents(odd)
+        tied = eng.activation_exponents()
+        assert tied[1] == tied[2] == max(base[1] + 5, base[2])                # ... and block 1 conv1 share one
+    finally:
+        eng.set_activation_exponents(base)
+
+
+def test_winograd_input_range_raises_the_flag(eng):
+    """conv_wino.hip re-splits V = BT d into f16 and that conversion saturates silently: a tensor it reads must stay
+    below 65504 / 8.5, so the launch that WRITES such a tensor raises the flag at 7,168 already.  Exponents 6 below
+    the calibration store maxima of ~16,000: inside f16, outside what the transform can take -- flagged with the
+    Winograd form on, clean (and right) with it off."""
+    mix, ca, cb = _clip(11, 0.25)
+    base = eng.activation_exponents()
+    try:
+        ref = eng.enhance([mix], [ca], [cb], want_mixed=False, taps=True)["logits"]
+        assert eng.take_status() == 0
+        eng.set_activation_exponents([e - 6 for e in base])
+        mix_t, mix_off = eng._dev([mix]); ca_t, ca_off = eng._dev([ca]); cb_t, cb_off = eng._dev([cb])
+        eng.enhance_device(mix_t, mix_off, ca_t, ca_off, cb_t, cb_off)
+        assert eng.take_status() & hip.STATUS_SATURATED
+        eng.set_option("winograd", 0)
+        got = eng.enhance_device(mix_t, mix_off, ca_t, ca_off, cb_t, cb_off, taps=True)["logits"].cpu().numpy()
+        assert eng.take_status() == 0
+        assert np.abs(got - ref).max() <= 2e-5
+    finally:
+        eng.set_option("winograd", 1)
+        eng.set_activation_exponents(base)
 
 
 def test_hip_round_trips_more_tensorflow_written_segments(eng):
