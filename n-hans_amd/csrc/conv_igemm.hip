@@ -122,17 +122,17 @@ __global__ void __launch_bounds__(256) conv_igemm(const ConvArgs a) {
     }
 #define NH_ADVANCE_A()                                                                             \
     {                                                                                              \
-        if (++kw >= sKW) {            /* K order (fold.py kmat): row, chunk, column, channel */    \
+        if (++kw >= sKW) {            /* K order (fold.py kmat): chunk, row, column, channel */    \
             kw = 0;                                                                                \
-            c0 += BK;                                                                              \
-            if (c0 >= sC) {                                                                        \
-                c0 = 0;                                                                            \
-                ++kh;                                                                              \
+            if (++kh >= sKH) {                                                                     \
+                kh = 0;                                                                            \
+                c0 += BK;                                                                          \
             }                                                                                      \
         }                                                                                          \
-        if (kh >= sKH) {                                                                           \
+        if (c0 >= sC) {                                                                           \
             ++seg;                                                                                 \
             if (seg < a.nseg) NH_ENTER_SEGMENT(seg)                                                \
+            else c0 = 0;              /* past the end: the cursor stays on valid memory */         \
         } else NH_TAP()                                                                            \
     }
 #define NH_LOAD_A(S)                                                                               \

@@ -120,17 +120,17 @@ __global__ void __launch_bounds__(512) conv_igemm_dma(const ConvArgs a) {
     }
 #define NH_ADVANCE_A()                                                                             \
     {                                                                                              \
-        if (++kw >= sKW) {            /* K order (fold.py kmat): row, chunk, column, channel */    \
+        if (++kw >= sKW) {            /* K order (fold.py kmat): chunk, row, column, channel */    \
             kw = 0;                                                                                \
-            c0 += DBK;                                                                             \
-            if (c0 >= sC) {                                                                        \
-                c0 = 0;                                                                            \
-                ++kh;                                                                              \
+            if (++kh >= sKH) {                                                                     \
+                kh = 0;                                                                            \
+                c0 += DBK;                                                                         \
             }                                                                                      \
         }                                                                                          \
-        if (kh >= sKH) {                                                                           \
+        if (c0 >= sC) {                                                                           \
             ++seg;                                                                                 \
             if (seg < a.nseg) NH_ENTER_SEGMENT(seg)                                                \
+            else c0 = 0;              /* past the end: the cursor stays on valid memory */         \
         } else NH_TAP()                                                                            \
     }
 
@@ -285,18 +285,18 @@ __global__ void __launch_bounds__(512) conv_igemm_dma(const ConvArgs a) {
     // prologue: chunks 0 and 1 in flight, wait for chunk 0 only
     long long t_loop = 0, t_epi = 0;
     NH_ENTER_SEGMENT(0)
-    if (cbeg) {                                        // cursor to chunk cbeg: K order (row, chunk, column)
+    if (cbeg) {                                        // cursor to chunk cbeg: K order (chunk, row, column)
         int cb_ = cbeg;
         if (cb_ >= n0chunks) {                         // the group starts inside the transform segment
             cb_ -= n0chunks;
             seg = 1;
             NH_ENTER_SEGMENT(1)
         }
-        const int per_kh = (sC >> 5) * sKW;
-        kh = cb_ / per_kh;
-        const int r_ = cb_ - kh * per_kh;
-        const int cc_ = r_ / sKW;
-        kw = r_ - cc_ * sKW;
+        const int per_cc = sKH * sKW;
+        const int cc_ = cb_ / per_cc;
+        const int r_ = cb_ - cc_ * per_cc;
+        kh = r_ / sKW;
+        kw = r_ - kh * sKW;
         c0 = cc_ * DBK;
         lchunk = cbeg;
         NH_TAP()

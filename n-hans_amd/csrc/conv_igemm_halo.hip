@@ -100,7 +100,10 @@ __global__ void __launch_bounds__((NCW + NPW) * 64) conv_igemm_halo(const ConvAr
     const int w0 = m0 - R0 * Wo;
 
     // segment shapes as scalars (segment 1 = optional 1x1 `_transform`); taps are walked in the order
-    // (segment, kh, 32-channel chunk, kw), which is the order fold.py kmat() packs the weights in
+    // (segment, 32-channel chunk, kh, kw), which is the order fold.py kmat() packs the weights in: the KH halo
+    // images of a chunk are the same pixels shifted by one image row, staged back to back, so all but the first come
+    // out of the L2 (in the order (kh, chunk) of rounds 1-2 a whole pass over the channels lay between them and every
+    // filter row fetched its image rows from HBM again: 2.2 x the algorithmic reads)
     const int nseg = a.nseg;
     const int KW0 = a.seg[0].KW, KH0 = a.seg[0].KH, CC0 = a.seg[0].C >> 5;
     const int KH1 = nseg > 1 ? a.seg[1].KH : 0, CC1 = nseg > 1 ? (a.seg[1].C >> 5) : 0;
@@ -197,10 +200,10 @@ __global__ void __launch_bounds__((NCW + NPW) * 64) conv_igemm_halo(const ConvAr
             if constexpr (!(ABL & 2)) NH_GLDS(p_, sa_ + d * 32 * 32)                               \
         }                                                                                          \
         ++supA;                                                                                    \
-        if (++ccA >= (segA ? CC1 : CC0)) {                                                         \
-            ccA = 0;                                                                               \
-            if (++khA >= (segA ? KH1 : KH0)) {                                                     \
-                khA = 0;                                                                           \
+        if (++khA >= (segA ? KH1 : KH0)) {        /* consecutive super-chunks shift by one row: L2 */ \
+            khA = 0;                                                                               \
+            if (++ccA >= (segA ? CC1 : CC0)) {                                                     \
+                ccA = 0;                                                                           \
                 if (segA == 0 && nseg > 1) {                                                       \
                     segA = 1;                                                                      \
                     NH_MAP_SEGMENT(1)                                                              \

@@ -14,8 +14,8 @@
 // that fall outside the image compute on whatever the rectangle holds and are dropped by the epilogue.
 //
 //   LDS: 2 image buffers x HR2 rows x 128 B + 4 weight stages x BN x 128 B (448 rows, BN 64: 144 KB).
-//   K order: channel chunk, filter row, filter column.  The packed weights are stored row, chunk,
-//   column (fold.py kmat); the producers' cursor jumps accordingly -- they have the issue slots.
+//   K order: channel chunk, filter row, filter column -- the order the packed weights are stored in
+//   (fold.py kmat) since round 3.
 //   One super-chunk = KH*KW >= 9 taps, so the standard counted waits of the halo kernel apply.
 //
 // Eligibility (launcher): one segment, stride 1, SAME padding, 64 output channels per tile column
@@ -130,14 +130,14 @@ __global__ void __launch_bounds__((T2_NCW + T2_NPW) * 64) conv_igemm_halo2d(cons
         }                                                                                          \
         ++ccA;                                                                                     \
     }
-        // weights of the taps in the order (chunk, row, column) out of an array packed (row, chunk, column)
+        // weights of the taps in the order (chunk, row, column) -- the order fold.py kmat() packs them in
         int kwB = 0, khB = 0, ccB = 0, tapB = 0;
         const float* const wbase = g.wpk + (size_t)nt0 * 1024;
         const float* bp_ = wbase;
 #define NH_ISSUE_B(ST)                                                                             \
     {                                                                                              \
         if (tapB < total) {                                                                        \
-            bp_ = wbase + (size_t)((khB * CC0 + ccB) * KW0 + kwB) * bstride;                       \
+            bp_ = wbase + (size_t)((ccB * KH0 + khB) * KW0 + kwB) * bstride;                       \
             ++tapB;                                                                                \
             if (++kwB >= KW0) {                                                                    \
                 kwB = 0;                                                                           \

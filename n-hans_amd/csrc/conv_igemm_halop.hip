@@ -206,10 +206,10 @@ __global__ void __launch_bounds__((NCW + NPW) * 64) conv_igemm_halo_persist(cons
         }                                                                                          \
         if (liveA) {                                                                               \
             ++supA;                                                                                \
-            if (++ccA >= (segA ? CC1 : CC0)) {                                                     \
-                ccA = 0;                                                                           \
-                if (++khA >= (segA ? KH1 : KH0)) {                                                 \
-                    khA = 0;                                                                       \
+            if (++khA >= (segA ? KH1 : KH0)) {                                                     \
+                khA = 0;                                                                           \
+                if (++ccA >= (segA ? CC1 : CC0)) {                                                 \
+                    ccA = 0;                                                                       \
                     if (segA == 0 && nseg > 1) {                                                   \
                         segA = 1;                                                                  \
                         NH_MAP_SEGMENT(1)                                                          \

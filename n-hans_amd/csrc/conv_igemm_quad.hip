@@ -68,7 +68,7 @@ __global__ void __launch_bounds__(QW * 64, 2) conv_igemm_quad(const ConvArgs a) 
     const int R0 = (int)fd_div((uint32_t)m0, a.fdWo);  // first output row (over all images) of the tile
     const int w0 = m0 - R0 * Wo;
 
-    // taps are walked in the order (segment, kh, 32-channel chunk, kw) -- fold.py kmat()
+    // taps are walked in the order (segment, 32-channel chunk, kh, kw) -- fold.py kmat()
     const int nseg = a.nseg;
     const int KW0 = a.seg[0].KW, KH0 = a.seg[0].KH, CC0 = a.seg[0].C >> 5;
     const int KH1 = nseg > 1 ? a.seg[1].KH : 0, CC1 = nseg > 1 ? (a.seg[1].C >> 5) : 0;
@@ -143,10 +143,10 @@ __global__ void __launch_bounds__(QW * 64, 2) conv_igemm_quad(const ConvArgs a) 
             NQ_GLDS(p_, sa_ + d * (QW * 8) * 32)                                                   \
         }                                                                                          \
         ++supA;                                                                                    \
-        if (++ccA >= (segA ? CC1 : CC0)) {                                                         \
-            ccA = 0;                                                                               \
-            if (++khA >= (segA ? KH1 : KH0)) {                                                     \
-                khA = 0;                                                                           \
+        if (++khA >= (segA ? KH1 : KH0)) {                                                         \
+            khA = 0;                                                                               \
+            if (++ccA >= (segA ? CC1 : CC0)) {                                                     \
+                ccA = 0;                                                                           \
                 if (segA == 0 && nseg > 1) {                                                       \
                     segA = 1;                                                                      \
                     NQ_MAP_SEGMENT(1)                                                              \

@@ -42,14 +42,15 @@ def _cont_embed(W, n, scope):
 
 
 def kmat(w4):
-    """HWIO conv weight [KH, KW, C, N] -> [K, N] in the K order the conv kernels walk: filter row,
-    32-channel chunk, filter column, channel within the chunk.  The KW taps of one (row, chunk) are
-    adjacent so that the halo kernel (conv_igemm_halo.hip) streams its weights strictly sequentially
-    while one staged activation image serves all KW of them.  (C = 1 convs are not GEMMs: plain order.)"""
+    """HWIO conv weight [KH, KW, C, N] -> [K, N] in the K order the conv kernels walk: 32-channel chunk, filter
+    row, filter column, channel within the chunk.  The KW taps of one (chunk, row) are adjacent so that the halo
+    kernel (conv_igemm_halo.hip) streams its weights strictly sequentially while one staged activation image serves
+    all KW of them, and the KH images of a chunk -- the same pixels shifted by one image row -- are staged back to
+    back, so that all but the first come out of the L2.  (C = 1 convs are not GEMMs: plain order.)"""
     kh, kw, c, n = w4.shape
     if c % 32:
         return w4.reshape(-1, n)
-    return w4.reshape(kh, kw, c // 32, 32, n).transpose(0, 2, 1, 3, 4).reshape(-1, n)
+    return w4.reshape(kh, kw, c // 32, 32, n).transpose(2, 0, 1, 3, 4).reshape(-1, n)
 
 
 def pack_igemm(wkn, npad=None):

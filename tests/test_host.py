@@ -123,8 +123,8 @@ def test_fold_blob_structure(weights_denoiser):
           np.sqrt(W["resblock1_2_conv1/pop_variance"].astype(np.float64) + 1e-3)).reshape(-1)
     w4 = W["resblock1_2_conv1/w"].astype(np.float64)
     w = fold.kmat(w4) * sc
-    # K order: filter row, 32-channel chunk, filter column, channel
-    assert w.shape == (4 * 4 * 64, 64) and w[(1 * 2 + 1) * 4 * 32 + 2 * 32 + 5, 7] == w4[1, 2, 32 + 5, 7] * sc[7]
+    # K order: 32-channel chunk, filter row, filter column, channel
+    assert w.shape == (4 * 4 * 64, 64) and w[((1 * 4 + 1) * 4 + 2) * 32 + 5, 7] == w4[1, 2, 32 + 5, 7] * sc[7]
     np.testing.assert_array_equal(arrs["m1.c1.wpk"], fold.pack_igemm(w))
     blob = fold.write_blob({"b": np.arange(5, dtype=np.float32), "a": np.ones(3, dtype=np.float32)})
     magic, ver, n, total = struct.unpack_from("<8sIIQ", blob, 0)
