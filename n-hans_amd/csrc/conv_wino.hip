@@ -36,6 +36,7 @@
 // loop assumes an even KH; the 3x3 layers' images fit F(6,3) tile blocks badly and stay on the direct kernel),
 // Cin % 16 == 0, N % 64 == 0, split-NHWC input and output.
 #include "conv_epilogue.h"
+#include <cstddef>
 
 #include <algorithm>
 
@@ -81,123 +82,217 @@ template <int SEL> __device__ __forceinline__ float unsplit_mix(float hi_pair, f
 }
 }  // namespace
 
-// Output transform + fused block epilogue of one thread = (tile-pixel q, 8 channels).  `ct` holds the eight
-// transformed-domain accumulator tiles M_p[64 tile-pixels][W_LDM] (channel 8a + 4b + c of a row at float b*32 + a*4 + c:
-// the eight threads of a tile-pixel read 128 contiguous bytes at a time).  The thread reads its 8 x 8 values ONCE and
-// forms all MO output columns Y_i = sum_p AT[i][p] M_p with the shared sums of the +-1, +-2, +-1/2 point pairs
-// (18 instead of 8*MO operations per channel); local pixel i*64 + q is output column i of tile-pixel q.
+// A field of the kernel's ConvArgs read from the kernarg segment with a scalar load at the point of use.  The compiler
+// otherwise parks the fields the epilogue needs (scales, saturation limit and flag pointer) in SCRATCH at kernel entry
+// -- the K loop leaves it no registers -- and reloads them with scratch_load, which counts in vmcnt like every vector
+// load: the reload in front of the column loop then waits for everything in flight (s_waitcnt vmcnt(0)).
+template <typename T> __device__ __forceinline__ T wino_karg(size_t offset) {
+    typedef const __attribute__((address_space(4))) char* kptr;
+    return *reinterpret_cast<const __attribute__((address_space(4))) T*>((kptr)__builtin_amdgcn_kernarg_segment_ptr() + offset);
+}
+#define WINO_KARG(FIELD) wino_karg<decltype(ConvArgs::FIELD)>(offsetof(ConvArgs, FIELD))
+
+// Epilogue of a consumer thread: the wave's accumulator tiles M_p go to LDS, then the thread = (tile-pixel q, 8
+// channels) forms its MO output columns and runs the fused block epilogue on them.
+//   * `ct` holds the eight transformed-domain tiles M_p[64 tile-pixels][W_LDM] (channel 8a + 4b + c of a row at float
+//     b*32 + a*4 + c: the eight threads of a tile-pixel read 128 contiguous bytes at a time).  The thread reads its
+//     8 x 8 values ONCE and forms all MO columns Y_i = sum_p AT[i][p] M_p with the shared sums of the +-1, +-2, +-1/2
+//     point pairs (18 instead of 8*MO operations per channel), two channels at a time, and applies the first step of
+//     the block epilogue, fma(y, ws, bias), on the spot.
+//   * The MO columns of a tile-pixel are MO consecutive pixels of one image row of ONE frame: every address is a
+//     uniform frame base (scalar registers) + one 32-bit offset + a column stride, instead of a 64-bit pointer and a
+//     row-info record per column.  A column past the image's right edge (or a slot outside the block) loads from the
+//     thread's last valid pixel and is not stored.
+//   * The residual -- HBM, ~2,000 cycles away -- of ALL columns is requested BEFORE the accumulators go to LDS: the
+//     exchange, the barrier and the output transform run under that latency.  The position table (L2) follows one
+//     column ahead of its use.  Everything up to the two stores of a column is unconditional: with the arithmetic
+//     inside `if (valid)` the compiler sinks the (restrict) table loads into the branch, right in front of their use,
+//     with s_waitcnt vmcnt(0) -- one full memory latency per column, 2,750 cycles each, was what round 3's first
+//     version of this sweep spent.
 // IDM: 0 no residual, 1 split-NHWC tensor, 2 f32 NHWC tensor, 3 one-channel image.
 template <int IDM, int MO>
-__device__ __forceinline__ void wino_sweep(const ConvArgs& a, const float* ct, const int4* rowinfo, int q, int c8, int n,
-                                           long long* es) {
+__device__ __forceinline__ void wino_epilogue(const ConvArgs& a, const f32x16 (&acc)[2][2], float* ct, int p, int lane, int tid,
+                                              int b, int nb, int r0, int j0, int TR, int TJ, int cx, long long* es) {
+    const int g8 = lane >> 5;
+    const int c8 = tid & 7, q = tid >> 3;
+    const int n = nb * 64 + c8 * 8;
+    const int rr = q / TJ, tt = q - rr * TJ;
+    const int ho = r0 + rr, wo0 = (j0 + tt) * MO;
+    const bool okq = rr < TR && ho < a.Ho && j0 + tt < a.wino_ntile;
+    const int nvalid = okq ? (a.Wo - wo0 < MO ? a.Wo - wo0 : MO) : 0;       // columns of this tile-pixel inside the image
+    const int pix0 = okq ? ho * a.Wo + wo0 : 0;                                // first pixel, within the frame
+    const int lastc = nvalid > 0 ? nvalid - 1 : 0;
+    const int hoff = (n >> 5) * 64 + (n & 31);                                // half index inside a split-NHWC pixel
+    const size_t fpix = (size_t)b * a.Ho * a.Wo;                              // uniform
     const int f_tf = a.tf ? 1 : 0;
-    const float* __restrict__ tfp = a.tf ? a.tf : a.zero;
-    const int hoff = (n >> 5) * 64 + (n & 31);                 // half index inside a split-NHWC pixel
+    const char* const tfb = reinterpret_cast<const char*>(a.tf ? a.tf : a.zero);
     const float lo_clamp = a.relu ? 0.f : -3.0e38f;
-    bool sat = false;
 
-    // The residual (HBM: ~2,500 cycles under load) of a column is requested two columns ahead of its use -- the first
-    // two before the LDS reads of the output transform start --, the position table (L2) one column ahead; more in
-    // flight does not fit the register file (measured: the loaded values spill, with a wait in front of the spill).
-    Epi8Raw<IDM> r[MO];
-    auto request = [&](int i) {
-        const int4 ri = rowinfo[i * 64 + q];
-        r[i].m = ri.z;
-        const int mc = ri.z < 0 ? 0 : ri.z;
-        if constexpr (IDM == 1) {
-            const _Float16* hp = reinterpret_cast<const _Float16*>(a.id + (size_t)mc * a.id_ld) + hoff;
-            r[i].h = *reinterpret_cast<const f16x8*>(hp);
-            r[i].l = *reinterpret_cast<const f16x8*>(hp + 32);
-        } else if constexpr (IDM == 2) {                       // (the two 16-byte pieces ride in the h / l slots)
-            const float* fp = a.id + (size_t)mc * a.id_ld + n;
-            r[i].h = __builtin_bit_cast(f16x8, *reinterpret_cast<const f32x4*>(fp));
-            r[i].l = __builtin_bit_cast(f16x8, *reinterpret_cast<const f32x4*>(fp + 4));
-        } else if constexpr (IDM == 3) {
-            r[i].sv = a.id[ri.w];
-        }
-    };
-    constexpr int AHEAD = 2;                                   // (three does not fit the register file)
-#pragma unroll
-    for (int i = 0; i < AHEAD; ++i) request(i);
+    // 0. the per-channel constants (ws, bias, idw of the block's 64 channels), fetched by the eight threads of
+    // tile-pixel 0 BEFORE the residual requests -- loads return in order, so a constant fetched after them could not be
+    // used until every residual has arrived -- and handed to everybody through LDS with the accumulator tiles
+    float* const cst = ct + 8 * 64 * W_LDM;                    // [ws | bias | idw][64]
+    f32x4 ka[6];
+    if (q == 0) {
+        ka[0] = *reinterpret_cast<const f32x4*>(a.ws + n); ka[1] = *reinterpret_cast<const f32x4*>(a.ws + n + 4);
+        ka[2] = *reinterpret_cast<const f32x4*>(a.cb + cx + n); ka[3] = *reinterpret_cast<const f32x4*>(a.cb + cx + n + 4);
+        if constexpr (IDM != 0) { ka[4] = *reinterpret_cast<const f32x4*>(a.idw + n); ka[5] = *reinterpret_cast<const f32x4*>(a.idw + n + 4); }
+    }
     __builtin_amdgcn_sched_barrier(0);
-    // two channels at a time (8 x 8-byte LDS reads): 16 live accumulator registers beside the 40 of the outputs
-    f32x2 y2[MO][4];
+
+    // 1. residual requests of all columns
+    f32x4 rh[MO], rl[MO];
+    float rsv[MO];
+    if constexpr (IDM == 1) {
+        const char* const idb = reinterpret_cast<const char*>(a.id + fpix * a.id_ld);
+        const uint32_t o0 = (uint32_t)pix0 * (uint32_t)a.id_ld * 4u + (uint32_t)hoff * 2u, st = (uint32_t)a.id_ld * 4u;
+#pragma unroll
+        for (int i = 0; i < MO; ++i) {
+            const uint32_t o = o0 + (uint32_t)(i < lastc ? i : lastc) * st;
+            rh[i] = *reinterpret_cast<const f32x4*>(idb + o);
+            rl[i] = *reinterpret_cast<const f32x4*>(idb + o + 64);
+        }
+    } else if constexpr (IDM == 2) {
+        const char* const idb = reinterpret_cast<const char*>(a.id + fpix * a.id_ld);
+        const uint32_t o0 = ((uint32_t)pix0 * (uint32_t)a.id_ld + (uint32_t)n) * 4u, st = (uint32_t)a.id_ld * 4u;
+#pragma unroll
+        for (int i = 0; i < MO; ++i) {
+            const uint32_t o = o0 + (uint32_t)(i < lastc ? i : lastc) * st;
+            rh[i] = *reinterpret_cast<const f32x4*>(idb + o);
+            rl[i] = *reinterpret_cast<const f32x4*>(idb + o + 16);
+        }
+    } else if constexpr (IDM == 3) {
+        const int ids0 = (b * a.idH + (okq ? ho : 0) * a.idsh) * a.idW + (okq ? wo0 : 0) * a.idsw;
+#pragma unroll
+        for (int i = 0; i < MO; ++i) rsv[i] = a.id[ids0 + (i < lastc ? i : lastc) * a.idsw];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+
+    // 2. accumulators -> LDS.  Channel n = 8a + 4b + c of the 64 sits at float b*32 + a*4 + c of its row: the sweep
+    // thread of channel group a reads two 16-byte pieces, and eight such threads cover 128 contiguous bytes each time
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) {
+                const f32x4 v = {acc[t][j][4 * q4], acc[t][j][4 * q4 + 1], acc[t][j][4 * q4 + 2], acc[t][j][4 * q4 + 3]};
+                *reinterpret_cast<f32x4*>(ct + (p * 64 + t * 32 + (lane & 31)) * W_LDM + g8 * 32 + (j * 4 + q4) * 4) = v;
+            }
+    if (q == 0) {
+        const float in_scale = WINO_KARG(in_scale), id_scale = WINO_KARG(id_scale);
+        *reinterpret_cast<f32x4*>(cst + c8 * 8) = ka[0] * in_scale; *reinterpret_cast<f32x4*>(cst + c8 * 8 + 4) = ka[1] * in_scale;
+        *reinterpret_cast<f32x4*>(cst + 64 + c8 * 8) = ka[2]; *reinterpret_cast<f32x4*>(cst + 64 + c8 * 8 + 4) = ka[3];
+        if constexpr (IDM != 0) {
+            *reinterpret_cast<f32x4*>(cst + 128 + c8 * 8) = ka[4] * id_scale; *reinterpret_cast<f32x4*>(cst + 128 + c8 * 8 + 4) = ka[5] * id_scale;
+        }
+    }
+    if (kDev && es) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); es[0] = (long long)__builtin_amdgcn_s_memtime(); }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                              // (raw: the residual loads stay in flight across it)
+    if (kDev && es) es[1] = (long long)__builtin_amdgcn_s_memtime();
+
+    // 3. output transform, two channels at a time (8 x 8-byte LDS reads), with fma(y, ws, bias) -- the first step of
+    // the block epilogue -- applied on the spot.  The MO results go straight BACK to LDS, into the slots of positions
+    // 0 .. MO-1 the thread has just read (nobody else touches the slots of its tile-pixel and channels): the column loop
+    // below then holds one column of outputs instead of MO, which is what lets the residual of all columns stay in
+    // registers.  (Stored tensors carry 2^-e: ConvArgs::in_scale / id_scale / out_scale.)
+    // the position table (L2): the first TAHEAD columns ahead of the transform, then TAHEAD columns ahead of their use
+    // (all MO at once do not fit the register file beside the residuals)
+    const uint32_t to0 = ((uint32_t)pix0 * (uint32_t)a.N + (uint32_t)n) * 4u * f_tf, tst = (uint32_t)a.N * 4u * f_tf;
+    f32x4 t0[MO], t1[MO];
+    auto table = [&](int i) {
+        const uint32_t o = to0 + (uint32_t)(i < lastc ? i : lastc) * tst;
+        t0[i] = *reinterpret_cast<const f32x4*>(tfb + o);
+        t1[i] = *reinterpret_cast<const f32x4*>(tfb + o + 16 * f_tf);
+    };
+    constexpr int TAHEAD = 2;
+#pragma unroll
+    for (int i = 0; i < TAHEAD; ++i) table(i);
+    __builtin_amdgcn_sched_barrier(0);
+    float* const my = ct + q * W_LDM + c8 * 4;                                // + position * 64 * W_LDM + (0 | 32)
 #pragma unroll
     for (int qt = 0; qt < 4; ++qt) {
+        float* const slot = my + (qt >> 1) * 32 + (qt & 1) * 2;
         f32x2 m[8];
 #pragma unroll
-        for (int pp = 0; pp < 8; ++pp)
-            m[pp] = *reinterpret_cast<const f32x2*>(ct + (pp * 64 + q) * W_LDM + (qt >> 1) * 32 + c8 * 4 + (qt & 1) * 2);
+        for (int pp = 0; pp < 8; ++pp) m[pp] = *reinterpret_cast<const f32x2*>(slot + pp * 64 * W_LDM);
+        const f32x2 ws2 = *reinterpret_cast<const f32x2*>(cst + c8 * 8 + 2 * qt);
+        const f32x2 hc2 = *reinterpret_cast<const f32x2*>(cst + 64 + c8 * 8 + 2 * qt);
         const f32x2 s12 = m[1] + m[2], d12 = m[1] - m[2], s34 = m[3] + m[4], d34 = m[3] - m[4], s56 = m[5] + m[6], d56 = m[5] - m[6];
-        y2[0][qt] = (m[0] + s12) + (s34 + s56);
-        y2[1][qt] = d12 + 2.f * d34 + 0.5f * d56;
-        y2[2][qt] = s12 + 4.f * s34 + 0.25f * s56;
-        y2[3][qt] = d12 + 8.f * d34 + 0.125f * d56;
+        f32x2 y[MO];
+        y[0] = (m[0] + s12) + (s34 + s56);
+        y[1] = d12 + 2.f * d34 + 0.5f * d56;
+        y[2] = s12 + 4.f * s34 + 0.25f * s56;
+        y[3] = d12 + 8.f * d34 + 0.125f * d56;
         if constexpr (MO == 5) {
-            y2[4][qt] = (s12 + m[7]) + 16.f * s34 + 0.0625f * s56;
+            y[4] = (s12 + m[7]) + 16.f * s34 + 0.0625f * s56;
         } else {
-            y2[4][qt] = s12 + 16.f * s34 + 0.0625f * s56;
-            y2[MO - 1][qt] = (d12 + m[7]) + 32.f * d34 + 0.03125f * d56;
+            y[4] = s12 + 16.f * s34 + 0.0625f * s56;
+            y[MO - 1] = (d12 + m[7]) + 32.f * d34 + 0.03125f * d56;
         }
+#pragma unroll
+        for (int i = 0; i < MO; ++i)
+            *reinterpret_cast<f32x2*>(slot + i * 64 * W_LDM) =
+                f32x2{__builtin_fmaf(y[i].x, ws2.x, hc2.x), __builtin_fmaf(y[i].y, ws2.y, hc2.y)};
         __builtin_amdgcn_sched_barrier(0);
     }
     if (kDev && es) es[2] = (long long)__builtin_amdgcn_s_memtime();
-    // (per-channel constants only now: they are not needed while the 8 x 8 accumulators are live)
-    // (stored tensors carry 2^-e: ConvArgs::in_scale / id_scale / out_scale)
-    const f32x4 ws0 = *reinterpret_cast<const f32x4*>(a.ws + n) * a.in_scale, ws1 = *reinterpret_cast<const f32x4*>(a.ws + n + 4) * a.in_scale;
+
+    // 4. columns
     f32x4 iw0 = {0.f, 0.f, 0.f, 0.f}, iw1 = iw0;
     if constexpr (IDM != 0) {
-        iw0 = *reinterpret_cast<const f32x4*>(a.idw + n) * a.id_scale;
-        iw1 = *reinterpret_cast<const f32x4*>(a.idw + n + 4) * a.id_scale;
+        iw0 = *reinterpret_cast<const f32x4*>(cst + 128 + c8 * 8);
+        iw1 = *reinterpret_cast<const f32x4*>(cst + 128 + c8 * 8 + 4);
     }
-    const float osc = a.out_scale, slim = a.sat_limit;
-    const int cx = rowinfo[0].x;                               // one frame = one clip: one bias vector
-    const f32x4 hc0 = *reinterpret_cast<const f32x4*>(a.cb + cx + n), hc1 = *reinterpret_cast<const f32x4*>(a.cb + cx + n + 4);
-    auto table = [&](int i) {                                  // position table of column i (L2-resident)
-        const int o = (rowinfo[i * 64 + q].y + n) * f_tf;
-        r[i].t0 = *reinterpret_cast<const f32x4*>(tfp + o);
-        r[i].t1 = *reinterpret_cast<const f32x4*>(tfp + o + 4 * f_tf);
-    };
-    table(0);
+    const float osc = WINO_KARG(out_scale), slim = WINO_KARG(sat_limit);
+    char* const outb = reinterpret_cast<char*>(a.out + fpix * a.ldo);
+    const uint32_t oo0 = (uint32_t)pix0 * (uint32_t)a.ldo * 4u + (uint32_t)hoff * 2u, ost = (uint32_t)a.ldo * 4u;
+    int sat = 0;
 #pragma unroll
     for (int i = 0; i < MO; ++i) {
-        if (i + AHEAD < MO) request(i + AHEAD);
-        if (i + 1 < MO) table(i + 1);
-        const f32x4 ya = {y2[i][0].x, y2[i][0].y, y2[i][1].x, y2[i][1].y}, yb = {y2[i][2].x, y2[i][2].y, y2[i][3].x, y2[i][3].y};
+        if (i + TAHEAD < MO) table(i + TAHEAD);
+        const f32x4 ya = *reinterpret_cast<const f32x4*>(my + i * 64 * W_LDM);
+        const f32x4 yb = *reinterpret_cast<const f32x4*>(my + i * 64 * W_LDM + 32);
         f32x4 i0 = {0.f, 0.f, 0.f, 0.f}, i1 = i0;
         if constexpr (IDM == 1) {
-            const f16x8 h = r[i].h, l = r[i].l;
-            i0 = f32x4{(float)h[0] + (float)l[0], (float)h[1] + (float)l[1], (float)h[2] + (float)l[2], (float)h[3] + (float)l[3]};
-            i1 = f32x4{(float)h[4] + (float)l[4], (float)h[5] + (float)l[5], (float)h[6] + (float)l[6], (float)h[7] + (float)l[7]};
+            // (float)hi + (float)lo, one v_fma_mix_f32 per value
+            i0 = f32x4{unsplit_mix<0>(rh[i].x, rl[i].x), unsplit_mix<1>(rh[i].x, rl[i].x), unsplit_mix<0>(rh[i].y, rl[i].y), unsplit_mix<1>(rh[i].y, rl[i].y)};
+            i1 = f32x4{unsplit_mix<0>(rh[i].z, rl[i].z), unsplit_mix<1>(rh[i].z, rl[i].z), unsplit_mix<0>(rh[i].w, rl[i].w), unsplit_mix<1>(rh[i].w, rl[i].w)};
         } else if constexpr (IDM == 2) {
-            i0 = __builtin_bit_cast(f32x4, r[i].h);
-            i1 = __builtin_bit_cast(f32x4, r[i].l);
+            i0 = rh[i];
+            i1 = rl[i];
         } else if constexpr (IDM == 3) {
-            i0 = f32x4{r[i].sv, r[i].sv, r[i].sv, r[i].sv};
+            i0 = f32x4{rsv[i], rsv[i], rsv[i], rsv[i]};
             i1 = i0;
         }
-        const f32x4 r0 = epi_combine(ya, ws0, hc0, r[i].t0, iw0, i0);
-        const f32x4 r1 = epi_combine(yb, ws1, hc1, r[i].t1, iw1, i1);
-        if (r[i].m >= 0) {
-            float yc[8];
+        const f32x4 r0v = fma4(iw0, i0, ya + t0[i]);           // (= epi_combine: ya already is fma(acc, ws, bias))
+        const f32x4 r1v = fma4(iw1, i1, yb + t1[i]);
+        const bool valid = i < nvalid;
+        float yc[8];
+        bool over = false;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const float v = fmaxf(e < 4 ? r0[e] : r1[e - 4], lo_clamp) * osc;
-                sat |= !(fabsf(v) < slim);
-                yc[e] = fminf(fmaxf(v, -65504.f), 65504.f);
-            }
-            uint4 hb, lb;
-            split_pair(yc[0], yc[1], &hb.x, &lb.x);
-            split_pair(yc[2], yc[3], &hb.y, &lb.y);
-            split_pair(yc[4], yc[5], &hb.z, &lb.z);
-            split_pair(yc[6], yc[7], &hb.w, &lb.w);
-            _Float16* dst = reinterpret_cast<_Float16*>(a.out + (size_t)r[i].m * a.ldo) + hoff;
-            *reinterpret_cast<uint4*>(dst) = hb;
-            *reinterpret_cast<uint4*>(dst + 32) = lb;
+        for (int e = 0; e < 8; ++e) {
+            const float v = fmaxf(e < 4 ? r0v[e] : r1v[e - 4], lo_clamp) * osc;
+            over |= !(fabsf(v) < slim);
+            yc[e] = __builtin_amdgcn_fmed3f(v, -65504.f, 65504.f);
         }
-        __builtin_amdgcn_sched_barrier(0);                     // (keeps the table loads one column ahead, not five)
+        sat |= (over && valid) ? 1 : 0;
+        asm volatile("" : "+v"(sat));                       // (here, not after the loop: the compiler would keep all 8*MO values alive for it)
+        uint4 hb, lb;
+        split_pair(yc[0], yc[1], &hb.x, &lb.x);
+        split_pair(yc[2], yc[3], &hb.y, &lb.y);
+        split_pair(yc[4], yc[5], &hb.z, &lb.z);
+        split_pair(yc[6], yc[7], &hb.w, &lb.w);
+        if (valid) {
+            char* dst = outb + (oo0 + (uint32_t)i * ost);
+            *reinterpret_cast<uint4*>(dst) = hb;
+            *reinterpret_cast<uint4*>(dst + 64) = lb;
+        }
+        __builtin_amdgcn_sched_barrier(0);                     // (column by column: bounded register pressure)
     }
-    if (sat && a.sat) atomicOr(a.sat, kSatActivation);
+    int* const satp = WINO_KARG(sat);
+    if (sat && satp) atomicOr(satp, kSatActivation);
 }
 
 template <int KH, int MO, int DBG = 0>      // DBG: dev tool, per-wave cycle stamps (tools/wino_phase_cycles.py)
@@ -378,6 +473,8 @@ __global__ void __launch_bounds__((WCW + WPW) * 64) conv_wino(const ConvArgs a) 
     // =============================================================================================
     // Consumer wave p = position p.
     const int p = wave;
+    // one frame = one clip: offset of its bias vector (uniform; fetched here, long before the epilogue needs it)
+    const int cbx = __builtin_amdgcn_readfirstlane((a.img_clip ? a.img_clip[b] : 0) * a.cb_stride);
     const int g8 = lane >> 5;
     const float* ub = a.wino_u + ((size_t)(nb * 8 + p) * NC * KH) * 1024 + lane * 4;
     const int aoff = (p * 4 + g8) * W_PLANE + (lane & 31) * 4;          // plane (p, hi, g8); lo: + 2*W_PLANE
@@ -451,47 +548,17 @@ __global__ void __launch_bounds__((WCW + WPW) * 64) conv_wino(const ConvArgs a) 
 #undef NW_READ_A
 #undef NW_MFMA
 
-    // ---- epilogue: M_p tiles -> LDS, output transform + fused block epilogue --------------------
-    float* ct = smem;
-    int4* rowinfo = reinterpret_cast<int4*>(smem + 8 * 64 * W_LDM);
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int q4 = 0; q4 < 4; ++q4) {
-                const f32x4 v = {acc[t][j][4 * q4], acc[t][j][4 * q4 + 1], acc[t][j][4 * q4 + 2], acc[t][j][4 * q4 + 3]};
-                // channel n = 8a + 4b + c of the 64 sits at float b*32 + a*4 + c of its row: the sweep thread of channel
-                // group a reads two 16-byte pieces, and eight such threads cover 128 contiguous bytes each time
-                *reinterpret_cast<f32x4*>(ct + (p * 64 + t * 32 + (lane & 31)) * W_LDM + g8 * 32 + (j * 4 + q4) * 4) = v;
-            }
-    // local pixel P = i*64 + q: output column i of tile-pixel q
-    for (int P = tid; P < 64 * MO; P += WCW * 64) {
-        const int i = P >> 6, q = P & 63;
-        const int r = q / TJ, t = q - r * TJ;
-        const int ho = r0 + r, wo = (j0 + t) * MO + i;
-        const bool ok = r < TR && ho < a.Ho && j0 + t < a.wino_ntile && wo < a.Wo;
-        const int rem = ok ? ho * a.Wo + wo : 0;                        // (slots that are not stored look like the frame's first pixel)
-        const int m = b * a.Ho * a.Wo + rem;
-        const int clip = a.img_clip ? a.img_clip[b] : 0;
-        const int hh = ok ? ho : 0, ww = ok ? wo : 0;
-        const int ids = (b * a.idH + hh * a.idsh) * a.idW + ww * a.idsw;
-        rowinfo[P] = make_int4(clip * a.cb_stride, rem * a.N, ok ? m : -1, ids);
-    }
-    long long es[3] = {0, 0, 0}, dbg_e0 = 0, dbg_e1 = 0;
-    if constexpr (DBG) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); dbg_e0 = (long long)__builtin_amdgcn_s_memtime(); }
-    __syncthreads();
-    if constexpr (DBG) dbg_e1 = (long long)__builtin_amdgcn_s_memtime();
-    const int c8 = tid & 7, prow8 = tid >> 3;
-    const int n8 = nb * 64 + c8 * 8;
-    switch (a.id_mode) {                                               // one frame = one clip: the bias is loaded once
-        case 0: wino_sweep<0, MO>(a, ct, rowinfo, prow8, c8, n8, DBG ? es : nullptr); break;
+    // ---- epilogue: residual requests, M_p tiles -> LDS, output transform + fused block epilogue ----
+    long long es[3] = {0, 0, 0};
+    switch (a.id_mode) {
+        case 0: wino_epilogue<0, MO>(a, acc, smem, p, lane, tid, b, nb, r0, j0, TR, TJ, cbx, DBG ? es : nullptr); break;
         case 1:
-            if (a.id_split) wino_sweep<1, MO>(a, ct, rowinfo, prow8, c8, n8, DBG ? es : nullptr);
-            else wino_sweep<2, MO>(a, ct, rowinfo, prow8, c8, n8, DBG ? es : nullptr);
+            if (a.id_split) wino_epilogue<1, MO>(a, acc, smem, p, lane, tid, b, nb, r0, j0, TR, TJ, cbx, DBG ? es : nullptr);
+            else wino_epilogue<2, MO>(a, acc, smem, p, lane, tid, b, nb, r0, j0, TR, TJ, cbx, DBG ? es : nullptr);
             break;
-        default: wino_sweep<3, MO>(a, ct, rowinfo, prow8, c8, n8, DBG ? es : nullptr); break;
+        default: wino_epilogue<3, MO>(a, acc, smem, p, lane, tid, b, nb, r0, j0, TR, TJ, cbx, DBG ? es : nullptr); break;
     }
+    const long long dbg_e0 = es[0], dbg_e1 = es[1];
     if constexpr (DBG) {                                                // [K loop, prologue wait, epilogue, barrier waits in the loop]
         const long long t_issued = (long long)__builtin_amdgcn_s_memtime();
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -507,7 +574,7 @@ __global__ void __launch_bounds__((WCW + WPW) * 64) conv_wino(const ConvArgs a) 
 }
 
 namespace {
-constexpr size_t kWinoLdsEpi = (size_t)(8 * 64 * W_LDM) * sizeof(float) + 64 * 6 * sizeof(int4);
+constexpr size_t kWinoLdsEpi = (size_t)(8 * 64 * W_LDM + 3 * 64) * sizeof(float);   // M tiles + the block's constants
 constexpr size_t kWinoLdsLoop = (size_t)(2 * W_VBUF + 2 * W_RAW) * sizeof(float);      // V and staged tiles, double-buffered
 constexpr size_t kWinoLds = kWinoLdsEpi > kWinoLdsLoop ? kWinoLdsEpi : kWinoLdsLoop;
 static_assert(kWinoLds <= 160 * 1024, "LDS of a gfx950 CU");

@@ -6,6 +6,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -276,7 +277,12 @@ void set_out_geometry(ConvArgs& a, int B, int Ho, int Wo, int N, int Nreal, int 
     a.fdWo = make_fastdiv((uint32_t)Wo);
 }
 
-void run_conv(nhans_ctx* c, const ConvArgs& a, hipStream_t s) {
+void run_conv(nhans_ctx* c, const ConvArgs& a0, hipStream_t s) {
+    ConvArgs a = a0;
+    if (kDev) {      // timing experiment (wrong results): NHANS_ABLATE_TF=1 -> no position table at all
+        static const bool no_tf = [] { const char* e = getenv("NHANS_ABLATE_TF"); return e && atoi(e) != 0; }();
+        if (no_tf) a.tf = nullptr;
+    }
     // profiled under the name of the kernel variant that ran (the variant is chosen per layer)
     Prof p(c, s, nullptr);
     const char* name = "conv_igemm";
