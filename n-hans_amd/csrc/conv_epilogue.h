@@ -15,6 +15,7 @@
 // channels, every table / residual read and every output write moves full 128-byte lines.
 #pragma once
 #include "nhans_kernels.h"
+#include <cstddef>
 
 namespace nhans {
 
@@ -67,6 +68,16 @@ __device__ __forceinline__ float split_load(const float* base, size_t row_floats
     return (float)p[0] + (float)p[32];
 }
 
+// A field of the kernel's ConvArgs (always the first kernel argument) read from the kernarg segment with a scalar load
+// at the point of use.  The compiler otherwise parks the fields an epilogue needs (scales, saturation limit and flag
+// pointer) in SCRATCH at kernel entry -- the K loops leave it no registers -- and reloads them with scratch_load, which
+// counts in vmcnt like every vector load: such a reload waits for everything in flight (s_waitcnt vmcnt(0)).
+template <typename T> __device__ __forceinline__ T conv_karg(size_t offset) {
+    typedef const __attribute__((address_space(4))) char* kptr;
+    return *reinterpret_cast<const __attribute__((address_space(4))) T*>((kptr)__builtin_amdgcn_kernarg_segment_ptr() + offset);
+}
+#define CONV_KARG(FIELD) ::nhans::conv_karg<decltype(::nhans::ConvArgs::FIELD)>(offsetof(::nhans::ConvArgs, FIELD))
+
 // LDS bytes the epilogue needs for a BMROWS x BNCOLS tile (accumulator tile padded by 4 floats per
 // row against bank conflicts + one int4 of row info per pixel)
 template <int BMROWS, int BNCOLS> constexpr size_t conv_epilogue_lds_bytes() {
@@ -103,11 +114,11 @@ __device__ __forceinline__ void conv_epilogue_sweep(const ConvArgs& a, const flo
     const float* __restrict__ cbp = a.cb;
     const float* __restrict__ tfp = a.tf ? a.tf : a.zero;     // an absent table reads the zero page
     f32x4 wsv = {1.f, 1.f, 1.f, 1.f}, idwv = {0.f, 0.f, 0.f, 0.f};
-    if constexpr (PREC == 1) wsv = *reinterpret_cast<const f32x4*>(a.ws + n) * a.in_scale;
-    if constexpr (IDM != 0) idwv = *reinterpret_cast<const f32x4*>(a.idw + n) * a.id_scale;
+    if constexpr (PREC == 1) wsv = *reinterpret_cast<const f32x4*>(a.ws + n) * CONV_KARG(in_scale);
+    if constexpr (IDM != 0) idwv = *reinterpret_cast<const f32x4*>(a.idw + n) * CONV_KARG(id_scale);
     const int hoff = (n >> 5) * 64 + (n & 31);                // half index inside a split-NHWC pixel
     const float lo_clamp = a.relu ? 0.f : -3.0e38f;           // branch-free ReLU
-    const float osc = a.out_scale;
+    const float osc = CONV_KARG(out_scale), slim = CONV_KARG(sat_limit);
     bool sat = false;                                         // split output: a value that does not fit f16
 #pragma unroll 1
     for (int pg = 0; pg < PASSES; pg += GP) {
@@ -145,7 +156,7 @@ __device__ __forceinline__ void conv_epilogue_sweep(const ConvArgs& a, const flo
                     f16x4 h, l;
                     float yc;
                     // (negated comparison: NaN counts as saturated too)
-                    sat |= !(fmaxf(fmaxf(fabsf(y.x), fabsf(y.y)), fmaxf(fabsf(y.z), fabsf(y.w))) < a.sat_limit);
+                    sat |= !(fmaxf(fmaxf(fabsf(y.x), fabsf(y.y)), fmaxf(fabsf(y.z), fabsf(y.w))) < slim);
                     yc = fminf(fmaxf(y.x, -65504.f), 65504.f); h.x = (_Float16)yc; l.x = (_Float16)(yc - (float)h.x);
                     yc = fminf(fmaxf(y.y, -65504.f), 65504.f); h.y = (_Float16)yc; l.y = (_Float16)(yc - (float)h.y);
                     yc = fminf(fmaxf(y.z, -65504.f), 65504.f); h.z = (_Float16)yc; l.z = (_Float16)(yc - (float)h.z);
@@ -161,7 +172,8 @@ __device__ __forceinline__ void conv_epilogue_sweep(const ConvArgs& a, const flo
     }
     if constexpr (OUTS) {
         // the split layout clamps to +-65504: tell the host (nhans_take_status) instead of going on silently
-        if (sat && a.sat) atomicOr(a.sat, kSatActivation);
+        int* const satp = CONV_KARG(sat);
+        if (sat && satp) atomicOr(satp, kSatActivation);
     }
 }
 
@@ -195,14 +207,16 @@ __device__ __forceinline__ void conv_epilogue_sweep8(const ConvArgs& a, const fl
     const float* __restrict__ tfp = a.tf ? a.tf : a.zero;
     f32x4 ws0 = {1.f, 1.f, 1.f, 1.f}, ws1 = ws0, iw0 = {0.f, 0.f, 0.f, 0.f}, iw1 = iw0;
     if constexpr (PREC == 1) {
-        ws0 = *reinterpret_cast<const f32x4*>(a.ws + n) * a.in_scale;
-        ws1 = *reinterpret_cast<const f32x4*>(a.ws + n + 4) * a.in_scale;
+        const float in_scale = CONV_KARG(in_scale);
+        ws0 = *reinterpret_cast<const f32x4*>(a.ws + n) * in_scale;
+        ws1 = *reinterpret_cast<const f32x4*>(a.ws + n + 4) * in_scale;
     }
     if constexpr (IDM != 0) {
-        iw0 = *reinterpret_cast<const f32x4*>(a.idw + n) * a.id_scale;
-        iw1 = *reinterpret_cast<const f32x4*>(a.idw + n + 4) * a.id_scale;
+        const float id_scale = CONV_KARG(id_scale);
+        iw0 = *reinterpret_cast<const f32x4*>(a.idw + n) * id_scale;
+        iw1 = *reinterpret_cast<const f32x4*>(a.idw + n + 4) * id_scale;
     }
-    const float osc = a.out_scale, slim = a.sat_limit;
+    const float osc = CONV_KARG(out_scale), slim = CONV_KARG(sat_limit);
     f32x4 hc0 = {0.f, 0.f, 0.f, 0.f}, hc1 = hc0;             // HOIST: the one clip's bias, loaded once
     if constexpr (HOIST) {
         const int cx = rowinfo[0].x;
@@ -211,7 +225,7 @@ __device__ __forceinline__ void conv_epilogue_sweep8(const ConvArgs& a, const fl
     }
     const int hoff = (n >> 5) * 64 + (n & 31);                // half index inside a split-NHWC pixel (n % 8 == 0)
     const float lo_clamp = a.relu ? 0.f : -3.0e38f;
-    bool sat = false;
+    int sat = 0;
 
     auto issue = [&](int g, Epi8Raw<IDM> (&r)[GP]) {
 #pragma unroll
@@ -253,16 +267,24 @@ __device__ __forceinline__ void conv_epilogue_sweep8(const ConvArgs& a, const fl
             const f32x4 c0 = HOIST ? hc0 : r[u].c0, c1 = HOIST ? hc1 : r[u].c1;
             const f32x4 r0 = epi_combine(av0, ws0, c0, r[u].t0, iw0, i0);
             const f32x4 r1 = epi_combine(av1, ws1, c1, r[u].t1, iw1, i1);
-            if (r[u].m >= 0) {
-                f16x8 h, l;
+            // Everything up to the two stores is unconditional (the saturation flag of a slot that is not stored is
+            // masked, not skipped): with the arithmetic inside `if (valid)` the compiler sinks the loads whose values
+            // are used only there -- the restrict position table, the bias -- into the branch, right in front of
+            // their use, and the software pipeline of issue() / finish() collapses into load, wait, store.
+            const bool valid = r[u].m >= 0;
+            f16x8 h, l;
+            bool over = false;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const float y = fmaxf(e < 4 ? r0[e] : r1[e - 4], lo_clamp) * osc;
-                    sat |= !(fabsf(y) < slim);
-                    const float yc = fminf(fmaxf(y, -65504.f), 65504.f);
-                    h[e] = (_Float16)yc;
-                    l[e] = (_Float16)(yc - (float)h[e]);
-                }
+            for (int e = 0; e < 8; ++e) {
+                const float y = fmaxf(e < 4 ? r0[e] : r1[e - 4], lo_clamp) * osc;
+                over |= !(fabsf(y) < slim);
+                const float yc = fminf(fmaxf(y, -65504.f), 65504.f);
+                h[e] = (_Float16)yc;
+                l[e] = (_Float16)(yc - (float)h[e]);
+            }
+            sat |= (over && valid) ? 1 : 0;
+            asm volatile("" : "+v"(sat));              // (here, not after the sweep: the values would stay alive for it)
+            if (valid) {
                 _Float16* dst = reinterpret_cast<_Float16*>(a.out + (size_t)r[u].m * a.ldo) + hoff;
                 *reinterpret_cast<f16x8*>(dst) = h;
                 *reinterpret_cast<f16x8*>(dst + 32) = l;
@@ -283,7 +305,8 @@ __device__ __forceinline__ void conv_epilogue_sweep8(const ConvArgs& a, const fl
         if (g + 2 < NG) issue(g + 2, ra);
         if (g + 1 < NG) finish(rb);
     }
-    if (sat && a.sat) atomicOr(a.sat, kSatActivation);
+    int* const satp = CONV_KARG(sat);
+    if (sat && satp) atomicOr(satp, kSatActivation);
 }
 
 // acc[i][j]: 32x32 MFMA tile (i: pixels, j: channels) of the wave whose tile-local origin is
@@ -372,6 +395,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[T
         }
     } else {
         // ragged output (last_dense: 201 of 256 columns, unaligned rows, optional pre-residual tap)
+        const float rg_in = CONV_KARG(in_scale), rg_id = CONV_KARG(id_scale), rg_out = CONV_KARG(out_scale);
         for (int ps = 0; ps < PASSES; ++ps) {
             const int p = ps * PP + prow;
             const int4 ri = rowinfo[p];
@@ -383,15 +407,15 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[T
                 const int ne = n + e;
                 if (ne >= a.Nreal) continue;
                 float x = ct[p * LDC + c4 * 4 + e];
-                x = __builtin_fmaf(x, PREC == 1 ? a.ws[ne] * a.in_scale : 1.f, cbp[ri.x + ne]) + tfp[(ri.y + ne) * f_tf];
+                x = __builtin_fmaf(x, PREC == 1 ? a.ws[ne] * rg_in : 1.f, cbp[ri.x + ne]) + tfp[(ri.y + ne) * f_tf];
                 float y = x;
-                const float iw = a.id_mode ? a.idw[ne] * a.id_scale : 0.f;
+                const float iw = a.id_mode ? a.idw[ne] * rg_id : 0.f;
                 if (a.id_mode == 1)
                     y = __builtin_fmaf(iw, id_split ? split_load(a.id, (size_t)m * a.id_ld, ne) : a.id[(size_t)m * a.id_ld + ne], y);
                 else if (a.id_mode == 2) y = __builtin_fmaf(iw, idsv, y);
                 if (a.relu) y = fmaxf(y, 0.f);
                 if (a.aux) a.aux[(size_t)m * a.aux_ld + ne] = x;
-                a.out[(size_t)m * a.ldo + ne] = y * a.out_scale;
+                a.out[(size_t)m * a.ldo + ne] = y * rg_out;
             }
         }
     }

@@ -82,16 +82,6 @@ template <int SEL> __device__ __forceinline__ float unsplit_mix(float hi_pair, f
 }
 }  // namespace
 
-// A field of the kernel's ConvArgs read from the kernarg segment with a scalar load at the point of use.  The compiler
-// otherwise parks the fields the epilogue needs (scales, saturation limit and flag pointer) in SCRATCH at kernel entry
-// -- the K loop leaves it no registers -- and reloads them with scratch_load, which counts in vmcnt like every vector
-// load: the reload in front of the column loop then waits for everything in flight (s_waitcnt vmcnt(0)).
-template <typename T> __device__ __forceinline__ T wino_karg(size_t offset) {
-    typedef const __attribute__((address_space(4))) char* kptr;
-    return *reinterpret_cast<const __attribute__((address_space(4))) T*>((kptr)__builtin_amdgcn_kernarg_segment_ptr() + offset);
-}
-#define WINO_KARG(FIELD) wino_karg<decltype(ConvArgs::FIELD)>(offsetof(ConvArgs, FIELD))
-
 // Epilogue of a consumer thread: the wave's accumulator tiles M_p go to LDS, then the thread = (tile-pixel q, 8
 // channels) forms its MO output columns and runs the fused block epilogue on them.
 //   * `ct` holds the eight transformed-domain tiles M_p[64 tile-pixels][W_LDM] (channel 8a + 4b + c of a row at float
@@ -180,7 +170,7 @@ __device__ __forceinline__ void wino_epilogue(const ConvArgs& a, const f32x16 (&
                 *reinterpret_cast<f32x4*>(ct + (p * 64 + t * 32 + (lane & 31)) * W_LDM + g8 * 32 + (j * 4 + q4) * 4) = v;
             }
     if (q == 0) {
-        const float in_scale = WINO_KARG(in_scale), id_scale = WINO_KARG(id_scale);
+        const float in_scale = CONV_KARG(in_scale), id_scale = CONV_KARG(id_scale);
         *reinterpret_cast<f32x4*>(cst + c8 * 8) = ka[0] * in_scale; *reinterpret_cast<f32x4*>(cst + c8 * 8 + 4) = ka[1] * in_scale;
         *reinterpret_cast<f32x4*>(cst + 64 + c8 * 8) = ka[2]; *reinterpret_cast<f32x4*>(cst + 64 + c8 * 8 + 4) = ka[3];
         if constexpr (IDM != 0) {
@@ -245,7 +235,7 @@ __device__ __forceinline__ void wino_epilogue(const ConvArgs& a, const f32x16 (&
         iw0 = *reinterpret_cast<const f32x4*>(cst + 128 + c8 * 8);
         iw1 = *reinterpret_cast<const f32x4*>(cst + 128 + c8 * 8 + 4);
     }
-    const float osc = WINO_KARG(out_scale), slim = WINO_KARG(sat_limit);
+    const float osc = CONV_KARG(out_scale), slim = CONV_KARG(sat_limit);
     char* const outb = reinterpret_cast<char*>(a.out + fpix * a.ldo);
     const uint32_t oo0 = (uint32_t)pix0 * (uint32_t)a.ldo * 4u + (uint32_t)hoff * 2u, ost = (uint32_t)a.ldo * 4u;
     int sat = 0;
@@ -291,7 +281,7 @@ __device__ __forceinline__ void wino_epilogue(const ConvArgs& a, const f32x16 (&
         }
         __builtin_amdgcn_sched_barrier(0);                     // (column by column: bounded register pressure)
     }
-    int* const satp = WINO_KARG(sat);
+    int* const satp = CONV_KARG(sat);
     if (sat && satp) atomicOr(satp, kSatActivation);
 }
 
