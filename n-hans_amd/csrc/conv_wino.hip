@@ -237,7 +237,9 @@ __device__ __forceinline__ void wino_epilogue(const ConvArgs& a, const f32x16 (&
     }
     const float osc = CONV_KARG(out_scale), slim = CONV_KARG(sat_limit);
     char* const outb = reinterpret_cast<char*>(a.out + fpix * a.ldo);
-    const uint32_t oo0 = (uint32_t)pix0 * (uint32_t)a.ldo * 4u + (uint32_t)hoff * 2u, ost = (uint32_t)a.ldo * 4u;
+    int n_again = n;                                           // (recomputed, not kept: one register fewer across the transform)
+    asm volatile("" : "+v"(n_again));
+    const uint32_t oo0 = (uint32_t)pix0 * (uint32_t)a.ldo * 4u + (uint32_t)((n_again >> 5) * 64 + (n_again & 31)) * 2u, ost = (uint32_t)a.ldo * 4u;
     int sat = 0;
 #pragma unroll
     for (int i = 0; i < MO; ++i) {
@@ -299,15 +301,34 @@ __global__ void __launch_bounds__((WCW + WPW) * 64) conv_wino(const ConvArgs a) 
         const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, idx = bid >> 3;
         L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
-    const int nnb = a.N >> 6;
-    const int nb = L % nnb;  L /= nnb;           // the channel blocks of one pixel block are neighbours (shared input in L2)
-    const int cb = L % a.wino_ncb;  L /= a.wino_ncb;
-    const int rb = L % a.wino_nrb;
-    const int b = L / a.wino_nrb;
+    // (frame, row block, column block, channel block), the channel blocks of one pixel block neighbours (shared input
+    // in L2); multiply-shift divisions -- this decode sits in front of every wave's first instruction
+    const int b = (int)fd_div((uint32_t)L, a.wino_fd_bpf);
+    const int lb = L - b * (int)a.wino_fd_bpf.d;
+    const int lt = (int)fd_div((uint32_t)lb, a.wino_fd_nnb);
+    const int nb = lb - lt * (int)a.wino_fd_nnb.d;
+    const int rb = (int)fd_div((uint32_t)lt, a.wino_fd_ncb);
+    const int cb = lt - rb * (int)a.wino_fd_ncb.d;
     const int TR = a.wino_tr, TJ = a.wino_tj;
     const int r0 = rb * TR, j0 = cb * TJ;
     const ConvSeg& g = a.seg[0];
     const int C = g.C, NC = C >> 4;              // 16-channel chunks
+
+    // Input tile of a chunk = 30 LDS-DMA wave-instructions: byte offset of this lane's 16-byte piece of instruction i
+    // within the frame, chunk 0 (0xFFFFFFFF: padding / unused slot -> zero page)
+    constexpr int NDMA = W_RAW / 4 / 64;
+    static_assert(NDMA == 30, "counted waits");
+    const char* const tile_fb = reinterpret_cast<const char*>(g.src + (size_t)b * g.H * g.W * C);
+    const char* const tile_zp = reinterpret_cast<const char*>(a.zero + lane * 4);
+    auto tile_offset = [&](int i) -> unsigned {
+        const int q = i * 64 + lane;
+        const int kind = q / (W_RROWS * W_RPX), rem = q - kind * (W_RROWS * W_RPX);
+        const int row = rem / W_RPX, px = rem - row * W_RPX;
+        const int hrow = r0 + row - g.pt, wcol = j0 * MO - g.pl + px;
+        const bool ok = row < TR + KH - 1 && px < TJ * MO + KH - 1 && (unsigned)hrow < (unsigned)g.H && (unsigned)wcol < (unsigned)g.W;
+        // split NHWC: a 32-channel group of a pixel is 64 B of hi halfs followed by 64 B of lo halfs
+        return ok ? (unsigned)(((hrow * g.W + wcol) * C) * 4 + (kind & 1) * 16 + (kind >> 1) * 64) : 0xFFFFFFFFu;
+    };
 
     if (wave >= WCW) {
         // =========================================================================================
@@ -321,21 +342,18 @@ __global__ void __launch_bounds__((WCW + WPW) * 64) conv_wino(const ConvArgs a) 
         const int nrows = TR + KH - 1;
         __builtin_amdgcn_s_setprio(3);                                // the waves everybody waits for
         if (wave == WCW + WPW - 1) {
-            constexpr int NDMA = W_RAW / 4 / 64;                      // 30 wave-instructions per tile
-            const int npx = TJ * MO + KH - 1;
+            const char* const fb = tile_fb;
+            const char* const zp = tile_zp;
             unsigned goff[NDMA];
 #pragma unroll
             for (int i = 0; i < NDMA; ++i) {
-                const int q = i * 64 + lane;
-                const int kind = q / (W_RROWS * W_RPX), rem = q - kind * (W_RROWS * W_RPX);
-                const int row = rem / W_RPX, px = rem - row * W_RPX;
-                const int hrow = r0 + row - g.pt, wcol = j0 * MO - g.pl + px;
-                const bool ok = row < nrows && px < npx && (unsigned)hrow < (unsigned)g.H && (unsigned)wcol < (unsigned)g.W;
-                // split NHWC: a 32-channel group of a pixel is 64 B of hi halfs followed by 64 B of lo halfs
-                goff[i] = ok ? (unsigned)(((hrow * g.W + wcol) * C) * 4 + (kind & 1) * 16 + (kind >> 1) * 64) : 0xFFFFFFFFu;
+                goff[i] = tile_offset(i);
+                // the piece of chunk 0 leaves at once: its memory latency runs under the remaining address arithmetic
+                // (all 30 offsets first, then 30 loads, put the first tile 1.5 k cycles later)
+                const char* s0 = goff[i] != 0xFFFFFFFFu ? fb + goff[i] : zp;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)s0,
+                                                 (__attribute__((address_space(3))) void*)(smem + W_RAW_BASE + i * 256), 16, 0, 0);
             }
-            const char* const fb = reinterpret_cast<const char*>(g.src + (size_t)b * g.H * g.W * C);
-            const char* const zp = reinterpret_cast<const char*>(a.zero + lane * 4);
 #define NW_DMA(CC, BUF)                                                                            \
     {                                                                                              \
         const unsigned co_ = (unsigned)((((CC) >> 1) * 32 + ((CC) & 1) * 8) * 4);                  \
@@ -346,9 +364,12 @@ __global__ void __launch_bounds__((WCW + WPW) * 64) conv_wino(const ConvArgs a) 
                                              (__attribute__((address_space(3))) void*)(dst_ + i * 256), 16, 0, 0); \
         }                                                                                          \
     }
-            // iteration it: the tile of chunk it+2 (its buffer was last read by the transform of chunk it, one iteration ago)
-            NW_DMA(0, 0)
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            // iteration cc: the tile of chunk cc+2 (its buffer was last read by the transform of chunk cc, one iteration
+            // ago); it must have landed when the iteration's barrier opens, because that barrier opens its transform.
+            // (Measured and rejected for the tile of chunk 1, whose round trip sits in front of the first MFMA: sent
+            // right behind the tile of chunk 0 by this wave, or by an idle consumer wave, it delays the tile of chunk 0
+            // by as much as it gains.)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // (chunk 0 was issued with the offsets)
             __builtin_amdgcn_s_barrier();
 #pragma unroll 1
             for (int cc = -1; cc < NC; ++cc) {
@@ -510,12 +531,15 @@ __global__ void __launch_bounds__((WCW + WPW) * 64) conv_wino(const ConvArgs a) 
                 }                                                                                  \
     }
     static_assert(KH == 4, "the weight ring is indexed by the filter row");
+    // Only the first k-step of weights is requested at kernel entry, the next two under the first transform (which
+    // uses LDS and the VALU, not the vector-memory path): all three at entry -- 96 KB per workgroup -- sat in the CU's
+    // memory queue in front of the 30 KB everybody is waiting for, the first input tile (it landed 1.7 k cycles later).
     NW_LOAD_B(0, 0)
-    NW_LOAD_B(1, 1)
-    NW_LOAD_B(2, 2)
     long long dbg_setup = 0;
     if constexpr (DBG) dbg_setup = (long long)__builtin_amdgcn_s_memtime() - dbg_entry;
     __builtin_amdgcn_s_barrier();                                       // the input tile of chunk 0 is staged
+    NW_LOAD_B(1, 1)
+    NW_LOAD_B(2, 2)
     __builtin_amdgcn_s_barrier();                                       // V of chunk 0 is in LDS
     long long dbg_t0 = 0, dbg_bar = 0, dbg_t1 = 0;
     if constexpr (DBG) dbg_t0 = (long long)__builtin_amdgcn_s_memtime();
@@ -611,6 +635,9 @@ static void wino_geometry(ConvArgs& a) {
     wino_block(a.Ho, a.wino_ntile, g.KH, a.wino_m, &a.wino_tr, &a.wino_tj);
     a.wino_nrb = (a.Ho + a.wino_tr - 1) / a.wino_tr;
     a.wino_ncb = (a.wino_ntile + a.wino_tj - 1) / a.wino_tj;
+    a.wino_fd_nnb = make_fastdiv((uint32_t)(a.N / 64));
+    a.wino_fd_ncb = make_fastdiv((uint32_t)a.wino_ncb);
+    a.wino_fd_bpf = make_fastdiv((uint32_t)(a.wino_nrb * a.wino_ncb * (a.N / 64)));
 }
 
 // MFMA FLOPs of the launch: every workgroup multiplies 8 positions x 64 tile-pixel slots (used or not) x 64 channels

@@ -157,6 +157,7 @@ struct ConvArgs {
     const float* wino_ws;
     int wino;
     int wino_m, wino_tr, wino_tj, wino_nrb, wino_ncb, wino_ntile;
+    FastDiv wino_fd_bpf, wino_fd_nnb, wino_fd_ncb;   // blocks per frame, channel blocks, column blocks (block decode)
     // 2-D pixel tiles (conv_igemm_halo2d.hip; filled in by its launcher): th x tw output pixels of one
     // image per workgroup, ntr x ntc tiles per image
     int t2_th, t2_tw, t2_ntr, t2_ntc;
