@@ -19,7 +19,7 @@ def main():
     frames = int(sys.argv[2]) if len(sys.argv) > 2 else 998
     eng = engine.Engine("denoiser", precision="f16x3")
     eng.set_option("winograd", 1)
-    mix = trim_to_frames(normalise(synth.mixture(0, 10.0)))
+    mix = trim_to_frames(normalise(synth.mixture(0, max(10.0, frames / 100.0 + 0.1))))
     lm, _ = eng.stft_features(torch.from_numpy(mix).cuda(), [0, len(mix)])
     ea = torch.zeros(1, 512, device="cuda")
     dbg = torch.zeros(8 * (1 << 20), dtype=torch.int64, device="cuda")
