@@ -138,7 +138,7 @@ __device__ __forceinline__ void wino_epilogue(const ConvArgs& a, const f32x16 (&
         const uint32_t o0 = (uint32_t)pix0 * (uint32_t)a.id_ld * 4u + (uint32_t)hoff * 2u, st = (uint32_t)a.id_ld * 4u;
 #pragma unroll
         for (int i = 0; i < MO; ++i) {
-            const uint32_t o = o0 + (uint32_t)(i < lastc ? i : lastc) * st;
+            const uint32_t o = (kDev && (a.wino_m >> 8 & 8)) ? (uint32_t)hoff * 2u : o0 + (uint32_t)(i < lastc ? i : lastc) * st;
             rh[i] = *reinterpret_cast<const f32x4*>(idb + o);
             rl[i] = *reinterpret_cast<const f32x4*>(idb + o + 64);
         }
@@ -276,7 +276,7 @@ __device__ __forceinline__ void wino_epilogue(const ConvArgs& a, const f32x16 (&
         split_pair(yc[2], yc[3], &hb.y, &lb.y);
         split_pair(yc[4], yc[5], &hb.z, &lb.z);
         split_pair(yc[6], yc[7], &hb.w, &lb.w);
-        if (valid) {
+        if (valid && !(kDev && (a.wino_m >> 8 & 8))) {
             char* dst = outb + (oo0 + (uint32_t)i * ost);
             *reinterpret_cast<uint4*>(dst) = hb;
             *reinterpret_cast<uint4*>(dst + 64) = lb;
@@ -359,7 +359,7 @@ __global__ void __launch_bounds__((WCW + WPW) * 64) conv_wino(const ConvArgs a) 
         const unsigned co_ = (unsigned)((((CC) >> 1) * 32 + ((CC) & 1) * 8) * 4);                  \
         float* dst_ = smem + W_RAW_BASE + (BUF) * W_RAW;                                           \
         _Pragma("unroll") for (int i = 0; i < NDMA; ++i) {                                         \
-            const char* s_ = goff[i] != 0xFFFFFFFFu ? fb + (goff[i] + co_) : zp;                   \
+            const char* s_ = (goff[i] != 0xFFFFFFFFu && !(kDev && (a.wino_m >> 8 & 1))) ? fb + (goff[i] + co_) : zp; \
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)s_,   \
                                              (__attribute__((address_space(3))) void*)(dst_ + i * 256), 16, 0, 0); \
         }                                                                                          \
@@ -654,8 +654,8 @@ void launch_conv_wino(const ConvArgs& a0, hipStream_t s) {
     wino_geometry(a);
     a.ws = a.wino_ws;
 #ifdef NHANS_DEV
-    // NHANS_ABLATE (timing experiments, wrong results): 1 producers never reload, 2 consumers skip the MFMAs,
-    // 4 producers transform the first chunk only
+    // NHANS_ABLATE (timing experiments, wrong results): 1 input tiles of chunks >= 1 from the zero page (no HBM reads),
+    // 2 consumers skip the MFMAs, 4 producers transform the first chunk only, 8 residual from one L2-hot line, no stores
     if (a.dbg) { a.wino_m |= (dev_ablate() & 15) << 8; launch_wino_t<4, 5, 1>(a, s); return; }
 #endif
     launch_wino_t<4, 5>(a, s);
