@@ -47,7 +47,11 @@ __global__ void __launch_bounds__(256) direct_conv64(const DirectArgs a) {
         const int clip = a.img_clip ? a.img_clip[b] : 0;
         const float4 cb = *reinterpret_cast<const float4*>(a.cb + (size_t)clip * a.cb_stride + c);
         acc.x += cb.x; acc.y += cb.y; acc.z += cb.z; acc.w += cb.w;
-        if (a.tf) {
+        if (a.tt) {                                       // the table's two terms (60 KB: cache-resident)
+            const float4 t = *reinterpret_cast<const float4*>(a.tt + ho * 64 + c);
+            const float4 f = *reinterpret_cast<const float4*>(a.ff + wo * 64 + c);
+            acc.x = (acc.x + t.x) + f.x; acc.y = (acc.y + t.y) + f.y; acc.z = (acc.z + t.z) + f.z; acc.w = (acc.w + t.w) + f.w;
+        } else if (a.tf) {
             const float4 t = *reinterpret_cast<const float4*>(a.tf + (size_t)rem * 64 + c);
             acc.x += t.x; acc.y += t.y; acc.z += t.z; acc.w += t.w;
         }
@@ -118,7 +122,11 @@ __global__ void __launch_bounds__(256) direct_conv64_4x4(const DirectArgs a, int
             const int rem = ho * a.Wo + wo;
             const size_t m = (size_t)b * a.Ho * a.Wo + rem;
             acc.x += cb.x; acc.y += cb.y; acc.z += cb.z; acc.w += cb.w;
-            if (a.tf) {
+            if (a.tt) {
+                const float4 t = *reinterpret_cast<const float4*>(a.tt + ho * 64 + c);
+                const float4 f = *reinterpret_cast<const float4*>(a.ff + wo * 64 + c);
+                acc.x = (acc.x + t.x) + f.x; acc.y = (acc.y + t.y) + f.y; acc.z = (acc.z + t.z) + f.z; acc.w = (acc.w + t.w) + f.w;
+            } else if (a.tf) {
                 const float4 t = *reinterpret_cast<const float4*>(a.tf + (size_t)rem * 64 + c);
                 acc.x += t.x; acc.y += t.y; acc.z += t.z; acc.w += t.w;
             }

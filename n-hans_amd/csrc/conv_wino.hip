@@ -114,19 +114,28 @@ __device__ __forceinline__ void wino_epilogue(const ConvArgs& a, const f32x16 (&
     const int lastc = nvalid > 0 ? nvalid - 1 : 0;
     const int hoff = (n >> 5) * 64 + (n & 31);                                // half index inside a split-NHWC pixel
     const size_t fpix = (size_t)b * a.Ho * a.Wo;                              // uniform
-    const int f_tf = a.tf ? 1 : 0;
-    const char* const tfb = reinterpret_cast<const char*>(a.tf ? a.tf : a.zero);
+    // position table = tt[ho] + ff[wo] (two small arrays: the [Ho*Wo, N] table of these layers, 1.8 MB, did not survive
+    // in L2 and came from HBM again almost once per frame).  An absent table reads the zero page.
+    const int f_tf = a.tt ? 1 : 0;
+    const char* const ffb = reinterpret_cast<const char*>(a.tt ? a.ff : a.zero);
     const float lo_clamp = a.relu ? 0.f : -3.0e38f;
 
     // 0. the per-channel constants (ws, bias, idw of the block's 64 channels), fetched by the eight threads of
     // tile-pixel 0 BEFORE the residual requests -- loads return in order, so a constant fetched after them could not be
     // used until every residual has arrived -- and handed to everybody through LDS with the accumulator tiles
-    float* const cst = ct + 8 * 64 * W_LDM;                    // [ws | bias | idw][64]
-    f32x4 ka[6];
+    // cst: [ws | idw][64], then per block row r: bias + tt[r0 + r] (the time term of the position table rides in the bias
+    // of the transform stage: v = fma(y, ws, bias + tt) + ff), fetched by the first tile-pixel of each row
+    float* const cst = ct + 8 * 64 * W_LDM;
+    f32x4 ka[4], kb[4];
+    const bool row_head = tt == 0 && rr < TR;
     if (q == 0) {
         ka[0] = *reinterpret_cast<const f32x4*>(a.ws + n); ka[1] = *reinterpret_cast<const f32x4*>(a.ws + n + 4);
-        ka[2] = *reinterpret_cast<const f32x4*>(a.cb + cx + n); ka[3] = *reinterpret_cast<const f32x4*>(a.cb + cx + n + 4);
-        if constexpr (IDM != 0) { ka[4] = *reinterpret_cast<const f32x4*>(a.idw + n); ka[5] = *reinterpret_cast<const f32x4*>(a.idw + n + 4); }
+        if constexpr (IDM != 0) { ka[2] = *reinterpret_cast<const f32x4*>(a.idw + n); ka[3] = *reinterpret_cast<const f32x4*>(a.idw + n + 4); }
+    }
+    if (row_head) {
+        const float* ttp = a.tt ? a.tt + (size_t)(ho < a.Ho ? ho : 0) * a.N + n : a.zero;
+        kb[0] = *reinterpret_cast<const f32x4*>(a.cb + cx + n); kb[1] = *reinterpret_cast<const f32x4*>(a.cb + cx + n + 4);
+        kb[2] = *reinterpret_cast<const f32x4*>(ttp); kb[3] = *reinterpret_cast<const f32x4*>(ttp + 4 * f_tf);
     }
     __builtin_amdgcn_sched_barrier(0);
 
@@ -172,10 +181,13 @@ __device__ __forceinline__ void wino_epilogue(const ConvArgs& a, const f32x16 (&
     if (q == 0) {
         const float in_scale = CONV_KARG(in_scale), id_scale = CONV_KARG(id_scale);
         *reinterpret_cast<f32x4*>(cst + c8 * 8) = ka[0] * in_scale; *reinterpret_cast<f32x4*>(cst + c8 * 8 + 4) = ka[1] * in_scale;
-        *reinterpret_cast<f32x4*>(cst + 64 + c8 * 8) = ka[2]; *reinterpret_cast<f32x4*>(cst + 64 + c8 * 8 + 4) = ka[3];
         if constexpr (IDM != 0) {
-            *reinterpret_cast<f32x4*>(cst + 128 + c8 * 8) = ka[4] * id_scale; *reinterpret_cast<f32x4*>(cst + 128 + c8 * 8 + 4) = ka[5] * id_scale;
+            *reinterpret_cast<f32x4*>(cst + 64 + c8 * 8) = ka[2] * id_scale; *reinterpret_cast<f32x4*>(cst + 64 + c8 * 8 + 4) = ka[3] * id_scale;
         }
+    }
+    if (row_head) {
+        *reinterpret_cast<f32x4*>(cst + (2 + rr) * 64 + c8 * 8) = kb[0] + kb[2];
+        *reinterpret_cast<f32x4*>(cst + (2 + rr) * 64 + c8 * 8 + 4) = kb[1] + kb[3];
     }
     if (kDev && es) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); es[0] = (long long)__builtin_amdgcn_s_memtime(); }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -189,12 +201,12 @@ __device__ __forceinline__ void wino_epilogue(const ConvArgs& a, const f32x16 (&
     // registers.  (Stored tensors carry 2^-e: ConvArgs::in_scale / id_scale / out_scale.)
     // the position table (L2): the first TAHEAD columns ahead of the transform, then TAHEAD columns ahead of their use
     // (all MO at once do not fit the register file beside the residuals)
-    const uint32_t to0 = ((uint32_t)pix0 * (uint32_t)a.N + (uint32_t)n) * 4u * f_tf, tst = (uint32_t)a.N * 4u * f_tf;
+    const uint32_t to0 = ((uint32_t)(okq ? wo0 : 0) * (uint32_t)a.N + (uint32_t)n) * 4u * f_tf, tst = (uint32_t)a.N * 4u * f_tf;
     f32x4 t0[MO], t1[MO];
     auto table = [&](int i) {
         const uint32_t o = to0 + (uint32_t)(i < lastc ? i : lastc) * tst;
-        t0[i] = *reinterpret_cast<const f32x4*>(tfb + o);
-        t1[i] = *reinterpret_cast<const f32x4*>(tfb + o + 16 * f_tf);
+        t0[i] = *reinterpret_cast<const f32x4*>(ffb + o);
+        t1[i] = *reinterpret_cast<const f32x4*>(ffb + o + 16 * f_tf);
     };
     constexpr int TAHEAD = 2;
 #pragma unroll
@@ -208,7 +220,7 @@ __device__ __forceinline__ void wino_epilogue(const ConvArgs& a, const f32x16 (&
 #pragma unroll
         for (int pp = 0; pp < 8; ++pp) m[pp] = *reinterpret_cast<const f32x2*>(slot + pp * 64 * W_LDM);
         const f32x2 ws2 = *reinterpret_cast<const f32x2*>(cst + c8 * 8 + 2 * qt);
-        const f32x2 hc2 = *reinterpret_cast<const f32x2*>(cst + 64 + c8 * 8 + 2 * qt);
+        const f32x2 hc2 = *reinterpret_cast<const f32x2*>(cst + (2 + (rr < TR ? rr : 0)) * 64 + c8 * 8 + 2 * qt);
         const f32x2 s12 = m[1] + m[2], d12 = m[1] - m[2], s34 = m[3] + m[4], d34 = m[3] - m[4], s56 = m[5] + m[6], d56 = m[5] - m[6];
         f32x2 y[MO];
         y[0] = (m[0] + s12) + (s34 + s56);
@@ -232,8 +244,8 @@ __device__ __forceinline__ void wino_epilogue(const ConvArgs& a, const f32x16 (&
     // 4. columns
     f32x4 iw0 = {0.f, 0.f, 0.f, 0.f}, iw1 = iw0;
     if constexpr (IDM != 0) {
-        iw0 = *reinterpret_cast<const f32x4*>(cst + 128 + c8 * 8);
-        iw1 = *reinterpret_cast<const f32x4*>(cst + 128 + c8 * 8 + 4);
+        iw0 = *reinterpret_cast<const f32x4*>(cst + 64 + c8 * 8);
+        iw1 = *reinterpret_cast<const f32x4*>(cst + 64 + c8 * 8 + 4);
     }
     const float osc = CONV_KARG(out_scale), slim = CONV_KARG(sat_limit);
     char* const outb = reinterpret_cast<char*>(a.out + fpix * a.ldo);
@@ -588,7 +600,7 @@ __global__ void __launch_bounds__((WCW + WPW) * 64) conv_wino(const ConvArgs a) 
 }
 
 namespace {
-constexpr size_t kWinoLdsEpi = (size_t)(8 * 64 * W_LDM + 3 * 64) * sizeof(float);   // M tiles + the block's constants
+constexpr size_t kWinoLdsEpi = (size_t)(8 * 64 * W_LDM + (2 + 64) * 64) * sizeof(float);   // M tiles + the block's constants (ws, idw, one bias row per block row)
 constexpr size_t kWinoLdsLoop = (size_t)(2 * W_VBUF + 2 * W_RAW) * sizeof(float);      // V and staged tiles, double-buffered
 constexpr size_t kWinoLds = kWinoLdsEpi > kWinoLdsLoop ? kWinoLdsEpi : kWinoLdsLoop;
 static_assert(kWinoLds <= 160 * 1024, "LDS of a gfx950 CU");
@@ -624,6 +636,7 @@ bool conv_wino_eligible(const ConvArgs& a) {
     if (g.C % 16 != 0 || a.N % 64 != 0 || a.Nreal != a.N || !a.out_split || a.aux) return false;
     if (a.id_mode == 1 && !a.id_split && (a.id_ld & 3)) return false;
     if (a.M % (a.Ho * a.Wo) != 0) return false;
+    if (a.tf && (!a.tt || !a.ff)) return false;                        // the epilogue reads the table's two terms
     // 32-bit element offsets inside the kernel
     return (double)a.M * std::max(g.C, a.N) + 65536.0 < 2147483648.0;
 }

@@ -244,7 +244,7 @@ struct Prof {
 void fill_epilogue_defaults(nhans_ctx* c, ConvArgs& a) {
     a.zero = c->A("zero");
     a.sat = c->status_dev;
-    a.img_clip = nullptr; a.tf = nullptr; a.id_mode = 0; a.id = nullptr; a.id_ld = 0;
+    a.img_clip = nullptr; a.tf = nullptr; a.tt = nullptr; a.ff = nullptr; a.id_mode = 0; a.id = nullptr; a.id_ld = 0;
     a.idw = nullptr; a.idH = a.idW = 0; a.idsh = a.idsw = 1; a.relu = 1; a.aux = nullptr; a.aux_ld = 0;
     a.cb_stride = 0;
     a.prec = c->prec; a.out_split = c->prec; a.id_split = 0; a.ws = nullptr;
@@ -281,7 +281,7 @@ void run_conv(nhans_ctx* c, const ConvArgs& a0, hipStream_t s) {
     ConvArgs a = a0;
     if (kDev) {      // timing experiment (wrong results): NHANS_ABLATE_TF=1 -> no position table at all
         static const bool no_tf = [] { const char* e = getenv("NHANS_ABLATE_TF"); return e && atoi(e) != 0; }();
-        if (no_tf) a.tf = nullptr;
+        if (no_tf) { a.tf = nullptr; a.tt = nullptr; a.ff = nullptr; }
     }
     // profiled under the name of the kernel variant that ran (the variant is chosen per layer)
     Prof p(c, s, nullptr);
@@ -322,7 +322,7 @@ int embed_impl(nhans_ctx* c, const float* ctx_lm, int n, float* emb_out, float* 
                 d.sh = g.sh; d.sw = g.sw;
                 int o; same_pad(g.hin, g.kh, g.sh, &o, &d.pt); same_pad(g.win, g.kw, g.sw, &o, &d.pl);
                 d.Ho = g.hout; d.Wo = g.wout; d.M = nc * g.hout * g.wout; d.out = a1;
-                d.cb = c->A(p + ".c1.cb"); d.cb_stride = 0; d.img_clip = nullptr; d.tf = nullptr;
+                d.cb = c->A(p + ".c1.cb"); d.cb_stride = 0; d.img_clip = nullptr; d.tf = nullptr; d.tt = nullptr; d.ff = nullptr;
                 d.relu = 1; d.fdHoWo = make_fastdiv(g.hout * g.wout); d.fdWo = make_fastdiv(g.wout);
                 d.out_split = c->prec; d.sat = c->status_dev; d.out_scale = c->down(TA(0, 0)); d.sat_limit = kSatLimitF16;
                 Prof pr(c, s, "direct_conv64");
@@ -436,7 +436,9 @@ float* run_stack_chunk(nhans_ctx* c, const float* logmag, const StackBufs& sb, i
             int o; same_pad(g.hin, g.kh, 1, &o, &d.pt); same_pad(g.win, g.kw, 1, &o, &d.pl);
             d.Ho = g.hout; d.Wo = g.wout; d.M = n * g.hout * g.wout; d.out = a1;
             d.cb = cb1; d.cb_stride = c->cond_cols; d.img_clip = clipmap;
-            d.tf = c->A(p + ".c1.tf"); d.relu = 1; d.out_split = c->prec; d.sat = c->status_dev;
+            d.tf = c->A(p + ".c1.tf"); d.tt = c->A(p + ".c1.tt"); d.ff = c->A(p + ".c1.ff");
+            if (!d.tt || !d.ff) d.tt = d.ff = nullptr;
+            d.relu = 1; d.out_split = c->prec; d.sat = c->status_dev;
             d.out_scale = c->down(SA(0, 0)); d.sat_limit = sat_limit_for(c, 0, 2);
             d.fdHoWo = make_fastdiv(g.hout * g.wout); d.fdWo = make_fastdiv(g.wout);
             Prof pr(c, s, "direct_conv64");
@@ -449,7 +451,7 @@ float* run_stack_chunk(nhans_ctx* c, const float* logmag, const StackBufs& sb, i
             a.seg[0] = make_seg(x, c->WP(p + ".c1.wpk"), g.hin, g.win, g.cin, g.kh, g.kw, g.sh, g.sw, true);
             set_out_geometry(a, n, g.hout, g.wout, g.cout, g.cout, g.cout, a1);
             a.cb = cb1; a.cb_stride = c->cond_cols; a.img_clip = clipmap;
-            a.tf = c->A(p + ".c1.tf");
+            a.tf = c->A(p + ".c1.tf"); a.tt = c->A(p + ".c1.tt"); a.ff = c->A(p + ".c1.ff");
             a.ws = c->WS(p + ".c1");
             a.wino_u = c->A(p + ".c1.wino"); a.wino_ws = c->A(p + ".c1.wino.ws");
             a.in_scale = c->up(SA(b - 1, 1)); a.out_scale = c->down(SA(b, 0));
@@ -462,7 +464,7 @@ float* run_stack_chunk(nhans_ctx* c, const float* logmag, const StackBufs& sb, i
         a.nseg = 1;
         a.seg[0] = make_seg(a1, c->WP(p + ".c2.wpk"), g.hout, g.wout, g.cout, g.kh, g.kw, 1, 1, true);
         a.cb = cb2; a.cb_stride = c->cond_cols; a.img_clip = clipmap;
-        a.tf = c->A(p + ".c2.tf");
+        a.tf = c->A(p + ".c2.tf"); a.tt = c->A(p + ".c2.tt"); a.ff = c->A(p + ".c2.ff");
         a.idw = c->A(p + ".c2.idw");
         a.ws = c->WS(p + ".c2");
         a.wino_u = c->A(p + ".c2.wino"); a.wino_ws = c->A(p + ".c2.wino.ws");

@@ -105,6 +105,8 @@ struct ConvArgs {
     int cb_stride;
     const int* img_clip;   // nullable -> clip 0
     const float* tf;       // nullable: time+frequency position table [Ho*Wo, N]
+    const float* tt;       // the same table's two terms on their own, [Ho, N] and [Wo, N] (conv_wino.hip reads these:
+    const float* ff;       // 60 KB instead of 1.8 MB per layer); nullable together
     int id_mode;
     const float* id;
     int id_ld;
@@ -197,6 +199,8 @@ struct DirectArgs {     // convolution of a 1-channel image into 64 channels, sa
     int cb_stride;
     const int* img_clip;
     const float* tf;    // [Ho*Wo,64] nullable
+    const float* tt;    // its two terms [Ho,64], [Wo,64]: used instead of tf when present (v = (acc + cb + tt) + ff)
+    const float* ff;
     int relu;
     int out_split;      // write split NHWC (hi/lo f16) instead of f32
     float out_scale;    // as ConvArgs::out_scale

@@ -301,6 +301,11 @@ def fold_arrays(W, kind, split_f16=True):
             tt = _cont_embed(W, g["hout"], q + "_temb") * sc
             ff = _cont_embed(W, g["wout"], q + "_femb") * sc
             out["%s.c%d.tf" % (p, cv)] = (tt[:, None, :] + ff[None, :, :]).reshape(-1)
+            # the two terms on their own (conv_wino.hip, direct_conv64: the big layers, whose [Ho*Wo, C] table -- 1.8 MB
+            # for 35 x 201 x 64 -- does not survive in a 4 MB L2 beside the streaming tensors and was re-fetched from
+            # HBM almost once per frame: 3.8 GB per launch)
+            out["%s.c%d.tt" % (p, cv)] = tt.reshape(-1)
+            out["%s.c%d.ff" % (p, cv)] = ff.reshape(-1)
             cond_w.append(np.concatenate([w64(q + ea + "/w"), w64(q + eb + "/w")], 0) * sc)
             cond_b.append(sc * (w64(q + ea + "/b").reshape(-1) + w64(q + eb + "/b").reshape(-1) + bias) + sh)
     out["cond.w"] = np.concatenate(cond_w, 1).reshape(-1)       # [1024, 3840]

@@ -117,6 +117,9 @@ def test_fold_blob_structure(weights_denoiser):
     assert arrs["m2.c2.wpk_t"].size == 64 * 128 and "m1.c2.wpk_t" not in arrs
     assert arrs["head.dense.wpk"].size == 13312 * 256
     assert arrs["m0.c1.tf"].size == 35 * 201 * 64 and arrs["m7.c2.tf"].size == 5 * 26 * 512
+    # ... and its two terms on their own: tf[h, w] == tt[h] + ff[w] up to the float32 rounding of the sum
+    tt, ff = arrs["m1.c2.tt"].reshape(35, 64), arrs["m1.c2.ff"].reshape(201, 64)
+    assert np.abs(arrs["m1.c2.tf"].reshape(35, 201, 64) - (tt[:, None, :] + ff[None, :, :])).max() <= 2e-6
     # BN scale really is folded: conv1 weights of block 1 equal w * gamma/sqrt(var+eps)
     W = weights_denoiser
     sc = (W["resblock1_2_conv1/gamma"].astype(np.float64) /
