@@ -69,8 +69,8 @@ __global__ void __launch_bounds__(256) direct_conv64(const DirectArgs a) {
             lo.x = (_Float16)(acc.x - (float)hi.x); lo.y = (_Float16)(acc.y - (float)hi.y);
             lo.z = (_Float16)(acc.z - (float)hi.z); lo.w = (_Float16)(acc.w - (float)hi.w);
             _Float16* line = reinterpret_cast<_Float16*>(a.out + (size_t)m * 64) + (c >> 5) * 64 + (c & 31);
-            *reinterpret_cast<h4*>(line) = hi;
-            *reinterpret_cast<h4*>(line + 32) = lo;
+            __builtin_nontemporal_store(hi, reinterpret_cast<h4*>(line));
+            __builtin_nontemporal_store(lo, reinterpret_cast<h4*>(line + 32));
         } else {
             *reinterpret_cast<float4*>(a.out + (size_t)m * 64 + c) = acc;
         }
@@ -143,8 +143,8 @@ __global__ void __launch_bounds__(256) direct_conv64_4x4(const DirectArgs a, int
                 lo.x = (_Float16)(acc.x - (float)hi.x); lo.y = (_Float16)(acc.y - (float)hi.y);
                 lo.z = (_Float16)(acc.z - (float)hi.z); lo.w = (_Float16)(acc.w - (float)hi.w);
                 _Float16* line = reinterpret_cast<_Float16*>(a.out + m * 64) + (c >> 5) * 64 + (c & 31);
-                *reinterpret_cast<h4*>(line) = hi;
-                *reinterpret_cast<h4*>(line + 32) = lo;
+                __builtin_nontemporal_store(hi, reinterpret_cast<h4*>(line));
+                __builtin_nontemporal_store(lo, reinterpret_cast<h4*>(line + 32));
             } else {
                 *reinterpret_cast<float4*>(a.out + m * 64 + c) = acc;
             }

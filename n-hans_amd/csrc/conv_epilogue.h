@@ -162,10 +162,10 @@ __device__ __forceinline__ void conv_epilogue_sweep(const ConvArgs& a, const flo
                     yc = fminf(fmaxf(y.z, -65504.f), 65504.f); h.z = (_Float16)yc; l.z = (_Float16)(yc - (float)h.z);
                     yc = fminf(fmaxf(y.w, -65504.f), 65504.f); h.w = (_Float16)yc; l.w = (_Float16)(yc - (float)h.w);
                     _Float16* dst = reinterpret_cast<_Float16*>(a.out + (size_t)m * a.ldo) + hoff;
-                    *reinterpret_cast<f16x4*>(dst) = h;
-                    *reinterpret_cast<f16x4*>(dst + 32) = l;
+                    __builtin_nontemporal_store(h, reinterpret_cast<f16x4*>(dst));
+                    __builtin_nontemporal_store(l, reinterpret_cast<f16x4*>(dst + 32));
                 } else {
-                    *reinterpret_cast<f32x4*>(a.out + (size_t)m * a.ldo + n) = y;
+                    __builtin_nontemporal_store(y, reinterpret_cast<f32x4*>(a.out + (size_t)m * a.ldo + n));
                 }
             }
         }
@@ -243,8 +243,8 @@ __device__ __forceinline__ void conv_epilogue_sweep8(const ConvArgs& a, const fl
             r[u].t1 = *reinterpret_cast<const f32x4*>(tfp + (ri.y + n) * f_tf + 4 * f_tf);
             if constexpr (IDM == 1) {
                 const _Float16* hp = reinterpret_cast<const _Float16*>(a.id + (size_t)mc * a.id_ld) + hoff;
-                r[u].h = *reinterpret_cast<const f16x8*>(hp);
-                r[u].l = *reinterpret_cast<const f16x8*>(hp + 32);
+                r[u].h = __builtin_nontemporal_load(reinterpret_cast<const f16x8*>(hp));     // (read once: keep the L2 for
+                r[u].l = __builtin_nontemporal_load(reinterpret_cast<const f16x8*>(hp + 32)); //  weights, tables and halos)
             } else if constexpr (IDM == 3) {
                 r[u].sv = a.id[ri.w];
             }
@@ -286,8 +286,8 @@ __device__ __forceinline__ void conv_epilogue_sweep8(const ConvArgs& a, const fl
             asm volatile("" : "+v"(sat));              // (here, not after the sweep: the values would stay alive for it)
             if (valid) {
                 _Float16* dst = reinterpret_cast<_Float16*>(a.out + (size_t)r[u].m * a.ldo) + hoff;
-                *reinterpret_cast<f16x8*>(dst) = h;
-                *reinterpret_cast<f16x8*>(dst + 32) = l;
+                __builtin_nontemporal_store(h, reinterpret_cast<f16x8*>(dst));                // (written once)
+                __builtin_nontemporal_store(l, reinterpret_cast<f16x8*>(dst + 32));
             }
         }
     };

@@ -148,8 +148,11 @@ __device__ __forceinline__ void wino_epilogue(const ConvArgs& a, const f32x16 (&
 #pragma unroll
         for (int i = 0; i < MO; ++i) {
             const uint32_t o = (kDev && (a.wino_m >> 8 & 8)) ? (uint32_t)hoff * 2u : o0 + (uint32_t)(i < lastc ? i : lastc) * st;
-            rh[i] = *reinterpret_cast<const f32x4*>(idb + o);
-            rl[i] = *reinterpret_cast<const f32x4*>(idb + o + 64);
+            // non-temporal: the residual is read once and the output written once -- left at the default policy these
+            // streams pushed the input tiles' halo rows (and the weights) out of the 4 MB L2 before the neighbouring
+            // workgroup came for them: with the hint the 64-channel layers' HBM reads equal their algorithmic bytes
+            rh[i] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(idb + o));
+            rl[i] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(idb + o + 64));
         }
     } else if constexpr (IDM == 2) {
         const char* const idb = reinterpret_cast<const char*>(a.id + fpix * a.id_ld);
@@ -157,8 +160,8 @@ __device__ __forceinline__ void wino_epilogue(const ConvArgs& a, const f32x16 (&
 #pragma unroll
         for (int i = 0; i < MO; ++i) {
             const uint32_t o = o0 + (uint32_t)(i < lastc ? i : lastc) * st;
-            rh[i] = *reinterpret_cast<const f32x4*>(idb + o);
-            rl[i] = *reinterpret_cast<const f32x4*>(idb + o + 16);
+            rh[i] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(idb + o));
+            rl[i] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(idb + o + 16));
         }
     } else if constexpr (IDM == 3) {
         const int ids0 = (b * a.idH + (okq ? ho : 0) * a.idsh) * a.idW + (okq ? wo0 : 0) * a.idsw;
@@ -290,8 +293,9 @@ __device__ __forceinline__ void wino_epilogue(const ConvArgs& a, const f32x16 (&
         split_pair(yc[6], yc[7], &hb.w, &lb.w);
         if (valid && !(kDev && (a.wino_m >> 8 & 8))) {
             char* dst = outb + (oo0 + (uint32_t)i * ost);
-            *reinterpret_cast<uint4*>(dst) = hb;
-            *reinterpret_cast<uint4*>(dst + 64) = lb;
+            typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+            __builtin_nontemporal_store(u32x4{hb.x, hb.y, hb.z, hb.w}, reinterpret_cast<u32x4*>(dst));   // (written once, read by the next launch)
+            __builtin_nontemporal_store(u32x4{lb.x, lb.y, lb.z, lb.w}, reinterpret_cast<u32x4*>(dst + 64));
         }
         __builtin_amdgcn_sched_barrier(0);                     // (column by column: bounded register pressure)
     }
