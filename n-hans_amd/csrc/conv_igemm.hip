@@ -362,6 +362,10 @@ double launch_conv_igemm(const ConvArgs& a0, hipStream_t s, const char** kernel,
         } else if (halo_ok && (a.halo64_tile512 = 0, conv_igemm_halo_eligible(a))) {
             if (wide && launch_conv_igemm_halo_persist(a, s)) name = "conv_igemm_halo_persist<128>";
             else { launch_conv_igemm_halo(a, s); name = wide ? "conv_igemm_halo<128>" : "conv_igemm_halo<64>"; }
+        } else if (halo_ok && wide && a.variant == 2 && conv_igemm_halo_pw_eligible(a)) {
+            // strided / VALID convs: the producer-consumer pipeline with one staged image per tap
+            launch_conv_igemm_halo_pw(a, s);
+            name = "conv_igemm_halo_pw<128>";
         } else {
             launch_conv_igemm_dma(a, s);
             name = a.kgroup < 0 ? (wide ? "conv_igemm_dma<128,grouped>" : "conv_igemm_dma<64,grouped>")

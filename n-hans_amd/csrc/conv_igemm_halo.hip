@@ -64,7 +64,13 @@ template <int N> __device__ __forceinline__ void halo_wait_vmcnt() {
 }
 }  // namespace
 
-template <int BN, int PREC, int HBM_ = 256, int DBG = 0, int ABL = 0>   // DBG: dev tool, per-workgroup cycle stamps (tools/halo_phase_cycles.py); ABL: timing ablations (wrong results)
+// PWM ("pointwise mode"): the same producer / consumer pipeline for the convs WITHOUT halo reuse -- strided convs, the
+// 5 x 1 VALID head conv -- that conv_igemm_dma.hip otherwise runs with every wave issuing DMA and MFMAs in lockstep.
+// Every tap (chunk, kh, kw) stages its own image of one 128-byte row per output pixel; with 256 rows instead of 320
+// THREE images fit beside the four weight stages (3 x 32 KB + 4 x 16 KB = the CU's 160 KB), so the image of tap it+2 is
+// issued while tap it is multiplied: one tap of lookahead where the two-buffer scheme of the 1 x 1 `_transform`
+// segment has none.
+template <int BN, int PREC, int HBM_ = 256, int DBG = 0, int ABL = 0, int PWM = 0>   // DBG: dev tool, per-workgroup cycle stamps (tools/halo_phase_cycles.py); ABL: timing ablations (wrong results)
 __global__ void __launch_bounds__((NCW + NPW) * 64) conv_igemm_halo(const ConvArgs a) {
     using SH = HaloShape<HBM_>;
     constexpr int HBM = SH::HBM, HR = SH::HR, BST = SH::BST, WN = SH::WN, NAP = SH::NAP;
@@ -72,9 +78,12 @@ __global__ void __launch_bounds__((NCW + NPW) * 64) conv_igemm_halo(const ConvAr
     constexpr int TM = 2;
     constexpr int TN = BN / (32 * WN);
     static_assert(HBM == (NCW / WN) * TM * 32 && BN == WN * TN * 32, "wave grid");
-    constexpr int A_BUF = HR * 32;                     // floats
+    static_assert(!PWM || (HBM == 256 && BST == 4), "pointwise mode: 256-pixel tiles, four weight stages");
+    constexpr int A_BUF = (PWM ? HBM : HR) * 32;       // floats
+    constexpr int NABUF = PWM ? 3 : 2;                 // image buffers
+    constexpr int NAPW = PWM ? HBM * 8 / (NPW * 64) : NAP;   // activation DMA instructions per producer thread per image
     constexpr int B_STAGE = 32 * BN;                   // floats
-    constexpr int B_BASE = 2 * A_BUF;
+    constexpr int B_BASE = NABUF * A_BUF;
     constexpr int GBP = B_STAGE / 4 / (NPW * 64);      // weight DMA instructions per producer thread per tap (4 / 2)
     extern __shared__ __attribute__((aligned(16))) float smem[];
 
@@ -107,15 +116,17 @@ __global__ void __launch_bounds__((NCW + NPW) * 64) conv_igemm_halo(const ConvAr
     const int nseg = a.nseg;
     const int KW0 = a.seg[0].KW, KH0 = a.seg[0].KH, CC0 = a.seg[0].C >> 5;
     const int KH1 = nseg > 1 ? a.seg[1].KH : 0, CC1 = nseg > 1 ? (a.seg[1].C >> 5) : 0;
-    const int nsup0 = KH0 * CC0;                       // super-chunks of segment 0
+    const int nsup0 = KH0 * CC0 * (PWM ? KW0 : 1);     // super-chunks (= staged images) of segment 0
     const int nsup = nsup0 + KH1 * CC1;
-    const int ntap0 = nsup0 * KW0;
+    const int ntap0 = PWM ? nsup0 : nsup0 * KW0;
     const int total = ntap0 + KH1 * CC1;               // taps = weight chunks
 
     // cursor of the current tap: segment, kw within the super-chunk, halo buffer, super-chunk count
     int segC = 0, kwC = 0, bufC = 0, supC = 0;
 #define NH_NEXT_TAP()                                                                              \
-    if (++kwC >= (segC ? 1 : KW0)) {                                                               \
+    if constexpr (PWM) {                                                                           \
+        bufC = bufC == NABUF - 1 ? 0 : bufC + 1;                                                   \
+    } else if (++kwC >= (segC ? 1 : KW0)) {                                                        \
         kwC = 0;                                                                                   \
         bufC ^= 1;                                                                                 \
         if (++supC == nsup0) segC = 1;                                                             \
@@ -146,19 +157,19 @@ __global__ void __launch_bounds__((NCW + NPW) * 64) conv_igemm_halo(const ConvAr
         // {r..r+3, r+12..r+15, r+20..r+27} of one fragment, and f = (row>>1)&7 makes those 16 slots
         // distinct for any r.  Per row: element offset of its pixel for kh = 0 / chunk 0 and the input
         // row hi0 of kh = 0, or a sentinel for padding / unused rows.
-        int poff[NAP], hov[NAP];
+        int poff[NAPW], hov[NAPW], wiv[PWM ? NAPW : 1];
         int sH = 0, sW = 0, sC = 0;
         const float* ssrc = nullptr;
 #define NH_MAP_SEGMENT(S)                                                                          \
     {                                                                                              \
         const ConvSeg& g = a.seg[S];                                                               \
         sH = g.H; sW = g.W; sC = g.C; ssrc = g.src;                                                \
-        _Pragma("unroll") for (int d = 0; d < NAP; ++d) {                                          \
+        _Pragma("unroll") for (int d = 0; d < NAPW; ++d) {                                         \
             const int j = d * 32 + pw * 8 + (lane >> 3);                                           \
             const int sp = (slot ^ ((j >> 1) & 7)) * 4;                                            \
             int Rg, wi;                                                                            \
             bool ok;                                                                               \
-            if (g.KW > 1) {                                                                        \
+            if (!PWM && g.KW > 1) {                                                                \
                 const int n0 = Wo - w0 + g.KW - 1;                                                 \
                 int i = 0, cj = w0 + j;                                                            \
                 if (j >= n0) {                                                                     \
@@ -181,6 +192,7 @@ __global__ void __launch_bounds__((NCW + NPW) * 64) conv_igemm_halo(const ConvAr
             const int hi0 = (Rg - b * a.Ho) * g.sh - g.pt;                                         \
             poff[d] = ((b * g.H + hi0) * g.W + wi) * g.C + sp;                                     \
             hov[d] = ok ? hi0 : -(1 << 28);                                                        \
+            if constexpr (PWM) wiv[d] = wi;              /* (column validity depends on the tap's kw) */ \
         }                                                                                          \
     }
 #define NH_GLDS(SRC, DST)                                                                          \
@@ -188,19 +200,22 @@ __global__ void __launch_bounds__((NCW + NPW) * 64) conv_igemm_halo(const ConvAr
                                      (__attribute__((address_space(3))) void*)(DST), 16, 0, 0);
 
         // activation cursor: next super-chunk to stage
-        int segA = 0, khA = 0, ccA = 0, supA = 0;
+        int segA = 0, khA = 0, ccA = 0, supA = 0, kwA = 0;
         const float* const zp = a.zero + (slot ^ ((lane >> 4) & 7)) * 4;   // any in-page offset will do
 #define NH_ISSUE_A(BUF)                                                                            \
     {                                                                                              \
-        const int khoff_ = khA * sW * sC + ccA * 32;                                               \
+        const int khoff_ = (khA * sW + (PWM ? kwA : 0)) * sC + ccA * 32;                           \
         const bool live_ = supA < nsup;                                                            \
         float* sa_ = smem + (BUF) * A_BUF + pw * 8 * 32;                                           \
-        _Pragma("unroll") for (int d = 0; d < NAP; ++d) {                                          \
-            const float* p_ = (!(ABL & 1) && live_ && (unsigned)(hov[d] + khA) < (unsigned)sH) ? ssrc + (poff[d] + khoff_) : zp; \
+        _Pragma("unroll") for (int d = 0; d < NAPW; ++d) {                                         \
+            bool in_ = !(ABL & 1) && live_ && (unsigned)(hov[d] + khA) < (unsigned)sH;             \
+            if constexpr (PWM) in_ = in_ && (unsigned)(wiv[d] + kwA) < (unsigned)sW;               \
+            const float* p_ = in_ ? ssrc + (poff[d] + khoff_) : zp;                                \
             if constexpr (!(ABL & 2)) NH_GLDS(p_, sa_ + d * 32 * 32)                               \
         }                                                                                          \
         ++supA;                                                                                    \
-        if (++khA >= (segA ? KH1 : KH0)) {        /* consecutive super-chunks shift by one row: L2 */ \
+        if (PWM && ++kwA < KW0) {                 /* pointwise: the KW taps of a filter row first */ \
+        } else if (kwA = 0, ++khA >= (segA ? KH1 : KH0)) { /* consecutive super-chunks shift by one row: L2 */ \
             khA = 0;                                                                               \
             if (++ccA >= (segA ? CC1 : CC0)) {                                                     \
                 ccA = 0;                                                                           \
@@ -229,9 +244,10 @@ __global__ void __launch_bounds__((NCW + NPW) * 64) conv_igemm_halo(const ConvAr
         NH_MAP_SEGMENT(0)
         NH_ISSUE_A(0)
         NH_ISSUE_B(0)
+        if constexpr (PWM) NH_ISSUE_A(1)                // (behind tap 0's weights: image 0 and tap 0 are what the barrier waits for)
         NH_ISSUE_B(1)
         if constexpr (PFD == 3) NH_ISSUE_B(2)
-        halo_wait_vmcnt<(PFD - 1) * GBP>();             // image 0 and tap 0
+        halo_wait_vmcnt<(PFD - 1) * GBP + (PWM ? NAPW : 0)>();   // image 0 and tap 0
         __builtin_amdgcn_s_barrier();
         long long dbg_is = 0, dbg_vm = 0, dbg_bar = 0, dbg_t0 = 0;
         if constexpr (DBG) dbg_t0 = (long long)__builtin_amdgcn_s_memtime();
@@ -242,11 +258,17 @@ __global__ void __launch_bounds__((NCW + NPW) * 64) conv_igemm_halo(const ConvAr
             const bool first = kwC == 0;
             long long tq0 = 0, tq1 = 0, tq2 = 0;
             if constexpr (DBG) tq0 = (long long)__builtin_amdgcn_s_memtime();
-            if (first) NH_ISSUE_A(bufC ^ 1)
+            if constexpr (PWM) {
+                // the image of tap it+2, into the buffer tap it-1 has released; behind it in the queue only the weights
+                // of tap it+3.  Needed at this iteration's barrier: image and weights of tap it+1 -- younger than those
+                // are the weights of tap it+2 (issued one iteration ago), this image and these weights.
+                NH_ISSUE_A(bufC == 0 ? NABUF - 1 : bufC - 1)
+            } else if (first) NH_ISSUE_A(bufC ^ 1)
             NH_ISSUE_B(stB)
             if (++stB == BST) stB = 0;
             if constexpr (DBG) tq1 = (long long)__builtin_amdgcn_s_memtime();
             if constexpr (ABL & (2 | 8)) halo_wait_vmcnt<0>();
+            else if constexpr (PWM) halo_wait_vmcnt<NAPW + 2 * GBP>();
             else if (KWc == 1) halo_wait_vmcnt<GBP>();
             else if (first || (PFD == 3 && prev_first)) halo_wait_vmcnt<(PFD - 1) * GBP + NAP>();
             else halo_wait_vmcnt<(PFD - 1) * GBP>();
@@ -301,7 +323,7 @@ __global__ void __launch_bounds__((NCW + NPW) * 64) conv_igemm_halo(const ConvAr
         const float* Sa_ = smem + bufC * A_BUF;                                                    \
         const float* Sb_ = smem + B_BASE + (STG) * B_STAGE + bcol;                                 \
         _Pragma("unroll") for (int t = 0; t < TM; ++t) {                                           \
-            const int jr_ = (segC ? jb1[t] : jb0[t]) + kwC;                                        \
+            const int jr_ = PWM ? jb1[t] : (segC ? jb1[t] : jb0[t]) + kwC;                         \
             const float* ar_ = Sa_ + jr_ * 32;                                                     \
             const int rs_ = (jr_ >> 1) & 7;                                                        \
             _Pragma("unroll") for (int s = (H) * KH_; s < ((H) + 1) * KH_; ++s) {                  \
@@ -427,7 +449,7 @@ __global__ void __launch_bounds__((NCW + NPW) * 64) conv_igemm_halo(const ConvAr
     long long dbg_epi = 0;
     long long es[3] = {0, 0, 0};
     if constexpr (DBG) dbg_epi = (long long)__builtin_amdgcn_s_memtime();
-    static_assert(conv_epilogue_lds_bytes<HBM, BN>() <= (size_t)(2 * A_BUF + BST * B_STAGE) * sizeof(float), "epilogue LDS");
+    static_assert(conv_epilogue_lds_bytes<HBM, BN>() <= (size_t)(NABUF * A_BUF + BST * B_STAGE) * sizeof(float), "epilogue LDS");
     conv_epilogue<TM, TN, PREC, NCW * 64, HBM, BN>(a, acc, smem, EpiTile{m0, 0, 0, 0, 0, 0}, wm * 64, wn * TN * 32, nt * BN, tid, lane,
                                                    DBG ? es : nullptr);
     if constexpr (DBG) {                                // [.., prologue cycles, epilogue cycles, ..]
@@ -443,15 +465,15 @@ __global__ void __launch_bounds__((NCW + NPW) * 64) conv_igemm_halo(const ConvAr
     }
 }
 
-template <int BN, int PREC, int HBM_ = 256, int DBG = 0, int ABL = 0> static void launch_halo_t(const ConvArgs& a, hipStream_t s) {
+template <int BN, int PREC, int HBM_ = 256, int DBG = 0, int ABL = 0, int PWM = 0> static void launch_halo_t(const ConvArgs& a, hipStream_t s) {
     using SH = HaloShape<HBM_>;
-    constexpr size_t lds = (size_t)(2 * SH::HR * 32 + SH::BST * 32 * BN) * sizeof(float);
+    constexpr size_t lds = (size_t)((PWM ? 3 * SH::HBM : 2 * SH::HR) * 32 + SH::BST * 32 * BN) * sizeof(float);
     static_assert(lds <= 160 * 1024, "LDS of a gfx950 CU");
     static unsigned long long attr_devices = 0;
-    set_max_dynamic_lds(reinterpret_cast<const void*>(&conv_igemm_halo<BN, PREC, HBM_, DBG, ABL>), lds, &attr_devices, "conv_igemm_halo");
+    set_max_dynamic_lds(reinterpret_cast<const void*>(&conv_igemm_halo<BN, PREC, HBM_, DBG, ABL, PWM>), lds, &attr_devices, "conv_igemm_halo");
     const int mtiles = (a.M + SH::HBM - 1) / SH::HBM;
     const int grid = mtiles * (a.N / BN);
-    NHANS_LAUNCH("conv_igemm_halo", (conv_igemm_halo<BN, PREC, HBM_, DBG, ABL>), dim3(grid), dim3((NCW + NPW) * 64), lds, s, a);
+    NHANS_LAUNCH("conv_igemm_halo", (conv_igemm_halo<BN, PREC, HBM_, DBG, ABL, PWM>), dim3(grid), dim3((NCW + NPW) * 64), lds, s, a);
 }
 
 // pixels per workgroup tile for this conv: 512 for the 64-channel layers, 256 otherwise
@@ -473,6 +495,21 @@ bool conv_igemm_halo_eligible(const ConvArgs& a) {
     const int hbm = halo_tile_pixels(a);
     const int nrows = (a.Wo - 1 + hbm - 1) / a.Wo + 1;
     return hbm + (g.KW - 1) * nrows <= (hbm == 512 ? HaloShape<512>::HR : HaloShape<256>::HR);
+}
+
+// Pointwise mode (template parameter PWM of the kernel): one segment, 128-channel tiles, any stride / padding / filter
+// shape, at least four taps; layers marked for grouped summation stay on conv_igemm_dma.hip.
+bool conv_igemm_halo_pw_eligible(const ConvArgs& a) {
+    const ConvSeg& g = a.seg[0];
+    if (a.nseg != 1 || a.N % 128 != 0 || a.kgroup != 0 || g.C % 32 != 0) return false;
+    if (g.KH * g.KW * (g.C / 32) < 4 || a.M % (a.Ho * a.Wo) != 0) return false;
+    const double elems = (double)(a.M / (a.Ho * a.Wo)) * g.H * g.W * g.C;      // 32-bit element offsets inside the kernel
+    return elems + 65536.0 < 2147483648.0 && (double)a.M * a.N < 2147483648.0;
+}
+
+void launch_conv_igemm_halo_pw(const ConvArgs& a, hipStream_t s) {
+    if (a.prec == 1) launch_halo_t<128, 1, 256, 0, 0, 1>(a, s);
+    else launch_halo_t<128, 0, 256, 0, 0, 1>(a, s);
 }
 
 void launch_conv_igemm_halo(const ConvArgs& a0, hipStream_t s) {

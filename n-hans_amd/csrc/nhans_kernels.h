@@ -175,6 +175,8 @@ bool conv_wino_eligible(const ConvArgs& a);                     // conv_wino.hip
 void launch_conv_wino(const ConvArgs& a, hipStream_t s);
 bool conv_igemm_halo_eligible(const ConvArgs& a);               // conv_igemm_halo.hip
 void launch_conv_igemm_halo(const ConvArgs& a, hipStream_t s);
+bool conv_igemm_halo_pw_eligible(const ConvArgs& a);            // the same pipeline without halo reuse (strided / VALID convs)
+void launch_conv_igemm_halo_pw(const ConvArgs& a, hipStream_t s);
 #ifdef NHANS_AB
 bool conv_igemm_quad_eligible(const ConvArgs& a);                         // conv_igemm_quad.hip
 void launch_conv_igemm_quad(const ConvArgs& a, hipStream_t s);
