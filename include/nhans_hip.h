@@ -96,7 +96,8 @@ void nhans_destroy(nhans_ctx* ctx);
  *           FP32-class accuracy, activations must stay below the f16 range 65504),
  *          "conv_variant" (-1: automatic, default; 0: register-staged 128-pixel kernel; 1: LDS-DMA
  *           256-pixel kernel; 2: halo-reuse kernel with producer/consumer waves where the conv
- *           allows it (512-pixel tiles for the 64-channel convs), else 1; 3: as 2 with the
+ *           allows it (512-pixel tiles for the 64-channel convs), the same pipeline with one staged image per tap
+ *           for the strided / VALID convs with >= 128 output channels, else 1; 3: as 2 with the
  *           64-channel convs on 2-D 256-pixel tiles -- same results within rounding, different speed).
  *          "epilogue_wide" (1, default: split-f16 epilogues move 8 channels = 16-byte pieces per thread;
  *           0: 4 channels -- identical bits, kept for A/B),
