@@ -156,3 +156,28 @@ def test_ten_minute_clip_and_the_per_clip_frame_limit(eng):
     rc = eng.lib.nhans_stft_features(eng.handle, hip.ptr(torch.zeros(8, device="cuda")), off, 1, 0,
                                      hip.ptr(torch.zeros(8, device="cuda")), None, None)
     assert rc == -1 and b"5000000" in eng.lib.nhans_last_error()
+
+
+def test_blob_without_the_tables_two_terms_still_runs(lib_built, weights_denoiser, monkeypatch):
+    """A folded blob from before the position table was also emitted as its two terms (`*.tt`, `*.ff`): the Winograd
+    kernel is then not eligible (it reads only the two terms) and `direct_conv64` reads the combined table -- same
+    logits to the f16x3 noise floor, no error."""
+    from nhans_amd import fold
+    mix = apply.trim_to_frames(apply.normalise(synth.mixture(5, 0.3)))
+    ca, cb = apply.normalise(synth.silent()), apply.normalise(synth.noise_context(5))
+    e = engine.Engine("denoiser", weights_denoiser, precision="f16x3")
+    ref = e.enhance([mix], [ca], [cb], want_mixed=False, taps=True)["logits"]
+    e.close()
+    full = fold.fold_arrays
+
+    def without_terms(W, kind, split_f16=True):
+        return {k: v for k, v in full(W, kind, split_f16).items() if not (k.endswith(".tt") or k.endswith(".ff"))}
+
+    monkeypatch.setattr(fold, "fold_arrays", without_terms)
+    e = engine.Engine("denoiser", weights_denoiser, precision="f16x3")
+    e.set_option("profile", 1)
+    got = e.enhance([mix], [ca], [cb], want_mixed=False, taps=True)["logits"]
+    names = set(e.profile().keys()) if isinstance(e.profile(), dict) else set()
+    e.close()
+    assert np.abs(got - ref).max() <= 2e-5
+    assert not any(n.startswith("conv_wino") for n in names)
