@@ -523,7 +523,7 @@ __global__ void __launch_bounds__((WCW + WPW) * 64) conv_wino(const ConvArgs a) 
     f32x4 fa[2][2];                         // [m-tile][hi|lo]
 #define NW_LOAD_B(RING, KS)                                                                        \
     {                                                                                              \
-        const float* u_ = ub + (size_t)((KS) < nks ? (KS) : nks - 1) * 1024;                       \
+        const float* u_ = ub + (size_t)((kDev && (a.wino_m >> 8 & 16)) ? 0 : (KS) < nks ? (KS) : nks - 1) * 1024; \
         _Pragma("unroll") for (int j = 0; j < 2; ++j)                                              \
             _Pragma("unroll") for (int h = 0; h < 2; ++h)                                          \
                 fb[RING][j][h] = *reinterpret_cast<const f32x4*>(u_ + (j * 2 + h) * 256);          \
@@ -672,8 +672,8 @@ void launch_conv_wino(const ConvArgs& a0, hipStream_t s) {
     a.ws = a.wino_ws;
 #ifdef NHANS_DEV
     // NHANS_ABLATE (timing experiments, wrong results): 1 input tiles of chunks >= 1 from the zero page (no HBM reads),
-    // 2 consumers skip the MFMAs, 4 producers transform the first chunk only, 8 residual from one L2-hot line, no stores
-    if (a.dbg) { a.wino_m |= (dev_ablate() & 15) << 8; launch_wino_t<4, 5, 1>(a, s); return; }
+    // 2 consumers skip the MFMAs, 4 producers transform the first chunk only, 8 residual from one L2-hot line, no stores, 16 every k-step loads the weights of k-step 0 (L1-resident)
+    if (a.dbg) { a.wino_m |= (dev_ablate() & 31) << 8; launch_wino_t<4, 5, 1>(a, s); return; }
 #endif
     launch_wino_t<4, 5>(a, s);
 }
