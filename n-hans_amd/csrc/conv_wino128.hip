@@ -1,0 +1,403 @@
+// The 1-D Winograd convolution of conv_wino.hip (F(5,4) along the image width, 8 transformed positions, plain
+// accumulation over filter rows and channels) with M = 128 tile-pixels per transformed-weight fragment.
+//
+// Why: conv_wino.hip's K loop is bound by the CU's vector-memory path, not by the matrix pipes (DESIGN.md section 4:
+// 5.9 k cycles per 16-channel chunk against an MFMA floor of 3.07 k).  Each of its 8 MFMA waves pulls its private
+// transformed weights U_p from L2 for only 64 tile-pixels -- 341 bytes per MFMA, 128 KB per chunk and CU, against the
+// ~31 B/clk that path delivers beside a running MFMA stream.  Here a weight fragment serves 128 tile-pixels (171 bytes
+// per MFMA), and the workgroup is rebuilt around what that costs:
+//
+//   * 128 accumulator registers per wave (4 x 2 MFMA tiles of one position) leave no room for specialised producer
+//     waves (twelve waves = 168 registers each): the workgroup is EIGHT waves at 256 registers, wave p = position p,
+//     and every wave also does an eighth of the input transform and of the tile staging.
+//   * The two waves of a SIMD (p, p + 4) run their phases in opposite order -- waves 0-3 multiply chunk c and then
+//     transform their share of chunk c + 1, waves 4-7 transform first and multiply afterwards -- so that each SIMD has
+//     one wave feeding the matrix pipe and one on the VALU / LDS at any time.  One barrier per chunk joins all eight.
+//   * A k-step of the MFMA (K = 16) is 8 channels x TWO filter rows (lanes 0-31 carry row 2s, lanes 32-63 row 2s + 1:
+//     the same V plane read at a slot offset of TJ), so a chunk is 8 channels, not 16: V of 150 slots x 8 positions x
+//     {hi, lo} is 38 KB, double-buffered 77 KB, and THREE staged input tiles of 25 KB fit beside it (the LDS-DMA round
+//     trip of a tile that comes from HBM is as long as a chunk: the DMA leads the transform by two chunks).
+//   * The accumulators of a workgroup are 256 KB: the epilogue (conv_wino_common.h) runs in two passes of 64
+//     tile-pixels.
+//
+// Per chunk and CU: 64 KB of weights + 25 KB of input through the vector-memory path for 3.07 k cycles of MFMA work
+// (29 B/clk; conv_wino.hip: 171 KB for the same 3.07 k).
+//
+// Transformed weights: fold.py pack_wino8 -- [N/64][p 8][C/8][s 2][nt 2][h 2][lane 64][e 8], lane l, element e of
+// k-step s of chunk c8 holds filter row 2s + (l >> 5), channel 8 c8 + e, column 64 nb + 32 nt + (l & 31).
+#include "conv_wino_common.h"
+
+namespace nhans {
+
+namespace {
+constexpr int XW = 8;                          // waves = transformed positions
+constexpr int X_NSLOT = 152;                   // (row, tile) slots per plane: >= 128 + (KH-1)*TJ
+constexpr int X_PLANE = X_NSLOT * 4 + 4;       // floats per plane (16 B = 8 channels of one half per slot)
+constexpr int X_VBUF = 16 * X_PLANE;           // floats per V buffer: 8 positions x {hi, lo}
+constexpr int X_RROWS = 21, X_RPX = 38;        // staged input tile of a chunk: rows (TR + KH - 1) x pixels (TJ*m + KH - 1)
+constexpr int X_RKIND = X_RROWS * X_RPX * 4;   // floats per piece kind (hi | lo): one 16-byte piece per (row, pixel)
+constexpr int X_NDMA = (2 * X_RROWS * X_RPX + 63) / 64;   // LDS-DMA wave-instructions per staged tile
+constexpr int X_DPW = (X_NDMA + XW - 1) / XW;  // ... per wave
+constexpr int X_RAW = X_NDMA * 256;            // floats per staged tile
+constexpr int X_RAW_BASE = 2 * X_VBUF;         // three staged tiles behind the two V buffers
+constexpr int X_DUMP = X_RAW_BASE + 3 * X_RAW; // 1 KB: target of the DMA slots that carry nothing
+static_assert(X_NDMA == 25 && X_DPW == 4, "counted waits");
+constexpr size_t kWino128LdsLoop = (size_t)(X_DUMP + 256) * sizeof(float);
+constexpr size_t kWino128Lds = kWinoLdsEpi > kWino128LdsLoop ? kWinoLdsEpi : kWino128LdsLoop;
+static_assert(kWino128Lds <= 160 * 1024, "LDS of a gfx950 CU");
+}  // namespace
+
+template <int KH, int MO, int DBG = 0>      // DBG: dev tool, per-wave cycle stamps (tools/wino_phase_cycles.py)
+__global__ void __launch_bounds__(XW * 64) conv_wino128(const ConvArgs a) {
+    static_assert(KH == 4, "a k-step pairs two filter rows");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    long long dbg_entry = 0;
+    if constexpr (DBG) dbg_entry = (long long)__builtin_amdgcn_s_memtime();
+    // XCD-aware, bijective remap of the linear workgroup id (each XCD owns a contiguous range of blocks)
+    int L;
+    {
+        const int nblk = gridDim.x, bid = blockIdx.x;
+        const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, idx = bid >> 3;
+        L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    // (frame, row block, column block, channel block), the channel blocks of one pixel block neighbours
+    const int b = (int)fd_div((uint32_t)L, a.wino_fd_bpf);
+    const int lb = L - b * (int)a.wino_fd_bpf.d;
+    const int lt = (int)fd_div((uint32_t)lb, a.wino_fd_nnb);
+    const int nb = lb - lt * (int)a.wino_fd_nnb.d;
+    const int rb = (int)fd_div((uint32_t)lt, a.wino_fd_ncb);
+    const int cb = lt - rb * (int)a.wino_fd_ncb.d;
+    const int TR = a.wino_tr, TJ = a.wino_tj;
+    const int r0 = rb * TR, j0 = cb * TJ;
+    const ConvSeg& g = a.seg[0];
+    const int C = g.C, NC = C >> 3;              // 8-channel chunks (even: C % 16 == 0)
+    const int nrows = TR + KH - 1;
+    const bool early = wave < XW / 2;            // (uniform) multiplies first, transforms afterwards
+
+    // ---- staging: this wave's X_DPW of the tile's X_NDMA LDS-DMA instructions (instruction i = wave + 8k) ----
+    // piece q = 64 i + lane = (kind, row, pixel); byte offset within the frame for chunk 0, or ~0: padding / unused
+    const char* const fbp = reinterpret_cast<const char*>(g.src + (size_t)b * g.H * g.W * C);
+    const char* const zp = reinterpret_cast<const char*>(a.zero + lane * 4);
+    unsigned goff[X_DPW];
+#pragma unroll
+    for (int k = 0; k < X_DPW; ++k) {
+        const int q = (wave + XW * k) * 64 + lane;
+        const int kind = q / (X_RROWS * X_RPX), rem = q - kind * (X_RROWS * X_RPX);
+        const int row = rem / X_RPX, px = rem - row * X_RPX;
+        const int hrow = r0 + row - g.pt, wcol = j0 * MO - g.pl + px;
+        const bool ok = kind < 2 && row < nrows && px < TJ * MO + KH - 1 && (unsigned)hrow < (unsigned)g.H && (unsigned)wcol < (unsigned)g.W;
+        // split NHWC: a 32-channel group of a pixel is 64 B of hi halfs followed by 64 B of lo halfs
+        goff[k] = ok ? (unsigned)(((hrow * g.W + wcol) * C) * 4 + kind * 64) : 0xFFFFFFFFu;
+    }
+    const bool last_real = wave + XW * (X_DPW - 1) < X_NDMA;     // (uniform) the wave's last slot carries pieces
+    // tile of chunk CC -> staged buffer RB (a chunk past the end: nothing, into the dump area)
+#define X_DMA(CC, RB)                                                                              \
+    {                                                                                              \
+        const int cc_ = (CC);                                                                      \
+        const bool live_ = cc_ < NC && !(kDev && (a.wino_m >> 8 & 1) && cc_ > 0);                  \
+        const unsigned co_ = (unsigned)((cc_ >> 2) * 128 + (cc_ & 3) * 16);                        \
+        float* const dst_ = smem + X_RAW_BASE + (RB) * X_RAW + wave * 256;                         \
+        _Pragma("unroll") for (int k = 0; k < X_DPW; ++k) {                                        \
+            const char* s_ = (goff[k] != 0xFFFFFFFFu && live_) ? fbp + (goff[k] + co_) : zp;       \
+            float* d_ = (cc_ < NC && (k < X_DPW - 1 || last_real)) ? dst_ + k * XW * 256 : smem + X_DUMP; \
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)s_,   \
+                                             (__attribute__((address_space(3))) void*)d_, 16, 0, 0); \
+        }                                                                                          \
+    }
+
+    // ---- transform: thread = (slot, 4 channels) = 8 pixels x 4 channels; the tasks are dealt to the waves in equal,
+    // contiguous shares so that a wave's lanes write consecutive 8-byte pieces of one plane ----
+    const int ntask = nrows * TJ * 2;
+    const int tpw = (ntask + XW - 1) / XW;
+    const int task = wave * tpw + lane;
+    const bool t_active = lane < tpw && task < ntask;
+    const int t_slot = t_active ? task >> 1 : 0, t_half = task & 1;
+    const int t_rs = t_slot / TJ, t_tj = t_slot - t_rs * TJ;
+    // LDS byte addresses (dynamic LDS starts at 0: the kernel has no static LDS)
+    const unsigned t_src = (unsigned)((X_RAW_BASE + (t_rs * X_RPX + t_tj * MO) * 4 + t_half * 2) * 4);   // + RB*X_RAW*4 (+ X_RKIND*4: lo)
+    const unsigned t_dst = (unsigned)((t_slot * 4 + t_half * 2) * 4);                                       // + VB*X_VBUF*4 + (p*2 + h)*X_PLANE*4
+    // BT, structured (fold.py: WINO_BT): even and odd parts of rows 1..6 share their sums; two channels at a time
+#define X_BT(D, V)                                                                                 \
+    {                                                                                              \
+        const f32x2 e1_ = D[2] + D[6] - 4.25f * D[4];                                              \
+        const f32x2 o1_ = D[1] + D[5] - 4.25f * D[3];                                              \
+        const f32x2 e2_ = 0.25f * D[2] - 1.25f * D[4] + D[6];                                      \
+        const f32x2 o2_ = 0.5f * D[1] - 2.5f * D[3] + 2.f * D[5];                                  \
+        const f32x2 e3_ = 4.f * D[2] - 5.f * D[4] + D[6];                                          \
+        const f32x2 o3_ = 2.f * D[1] - 2.5f * D[3] + 0.5f * D[5];                                  \
+        V[0] = 5.25f * (D[2] - D[4]) + (D[6] - D[0]);                                              \
+        V[1] = e1_ + o1_;  V[2] = e1_ - o1_;                                                       \
+        V[3] = e2_ + o2_;  V[4] = e2_ - o2_;                                                       \
+        V[5] = e3_ + o3_;  V[6] = e3_ - o3_;                                                       \
+        V[7] = 5.25f * (D[3] - D[5]) + (D[7] - D[1]);                                              \
+    }
+    // staged tile RB -> V buffer VB.  Every LDS access of the K loop is inline asm with hand-counted waits: the compiler
+    // makes ANY ds_read / ds_write it can see wait for all LDS-DMA requests of the same wave that are still in flight
+    // (it cannot tell the staged tiles from the V buffers: s_waitcnt vmcnt(0) in front of each) -- and the point of the
+    // three staged tiles is that two of them are in flight while the third is read.
+#define X_TRANSFORM(RB, VB)                                                                        \
+    if (t_active) {                                                                                \
+        const unsigned rs_ = t_src + (unsigned)((RB) * X_RAW * 4);                                 \
+        const unsigned vd_ = t_dst + (unsigned)((VB) * X_VBUF * 4);                                \
+        f32x2 rh_[8], rl_[8];                                                                      \
+        asm volatile(                                                                              \
+            "ds_read_b64 %0, %16\n ds_read_b64 %1, %16 offset:16\n ds_read_b64 %2, %16 offset:32\n ds_read_b64 %3, %16 offset:48\n" \
+            "ds_read_b64 %4, %16 offset:64\n ds_read_b64 %5, %16 offset:80\n ds_read_b64 %6, %16 offset:96\n ds_read_b64 %7, %16 offset:112\n" \
+            "ds_read_b64 %8, %16 offset:%17\n ds_read_b64 %9, %16 offset:%17+16\n ds_read_b64 %10, %16 offset:%17+32\n ds_read_b64 %11, %16 offset:%17+48\n" \
+            "ds_read_b64 %12, %16 offset:%17+64\n ds_read_b64 %13, %16 offset:%17+80\n ds_read_b64 %14, %16 offset:%17+96\n ds_read_b64 %15, %16 offset:%17+112\n" \
+            "s_waitcnt lgkmcnt(0)"                                                                 \
+            : "=&v"(rh_[0]), "=&v"(rh_[1]), "=&v"(rh_[2]), "=&v"(rh_[3]), "=&v"(rh_[4]), "=&v"(rh_[5]), "=&v"(rh_[6]), "=&v"(rh_[7]), \
+              "=&v"(rl_[0]), "=&v"(rl_[1]), "=&v"(rl_[2]), "=&v"(rl_[3]), "=&v"(rl_[4]), "=&v"(rl_[5]), "=&v"(rl_[6]), "=&v"(rl_[7]) \
+            : "v"(rs_), "n"(X_RKIND * 4) : "memory");                                              \
+        uint2 oh_[8], ol_[8];                                                                      \
+        _Pragma("unroll") for (int ep = 0; ep < 2; ++ep) {                                         \
+            f32x2 d_[8], v_[8];                                                                    \
+            _Pragma("unroll") for (int x = 0; x < 8; ++x) {                                        \
+                const float hp_ = rh_[x][ep], lp_ = rl_[x][ep];                                    \
+                d_[x] = f32x2{unsplit_mix<0>(hp_, lp_), unsplit_mix<1>(hp_, lp_)};                 \
+            }                                                                                      \
+            X_BT(d_, v_)                                                                           \
+            _Pragma("unroll") for (int pp = 0; pp < 8; ++pp) {                                     \
+                if (ep == 0) split_pair(v_[pp].x, v_[pp].y, &oh_[pp].x, &ol_[pp].x);               \
+                else split_pair(v_[pp].x, v_[pp].y, &oh_[pp].y, &ol_[pp].y);                       \
+            }                                                                                      \
+        }                                                                                          \
+        asm volatile(                                                                              \
+            "ds_write_b64 %16, %0\n ds_write_b64 %16, %1 offset:%17\n ds_write_b64 %16, %2 offset:%17*2\n ds_write_b64 %16, %3 offset:%17*3\n" \
+            "ds_write_b64 %16, %4 offset:%17*4\n ds_write_b64 %16, %5 offset:%17*5\n ds_write_b64 %16, %6 offset:%17*6\n ds_write_b64 %16, %7 offset:%17*7\n" \
+            "ds_write_b64 %16, %8 offset:%17*8\n ds_write_b64 %16, %9 offset:%17*9\n ds_write_b64 %16, %10 offset:%17*10\n ds_write_b64 %16, %11 offset:%17*11\n" \
+            "ds_write_b64 %16, %12 offset:%17*12\n ds_write_b64 %16, %13 offset:%17*13\n ds_write_b64 %16, %14 offset:%17*14\n ds_write_b64 %16, %15 offset:%17*15" \
+            :: "v"(oh_[0]), "v"(ol_[0]), "v"(oh_[1]), "v"(ol_[1]), "v"(oh_[2]), "v"(ol_[2]), "v"(oh_[3]), "v"(ol_[3]),          \
+               "v"(oh_[4]), "v"(ol_[4]), "v"(oh_[5]), "v"(ol_[5]), "v"(oh_[6]), "v"(ol_[6]), "v"(oh_[7]), "v"(ol_[7]),          \
+               "v"(vd_), "n"(X_PLANE * 4) : "memory");                                             \
+    }
+
+    // ---- multiply: position p = this wave ----
+    const int p = wave;
+    const int cbx = __builtin_amdgcn_readfirstlane((a.img_clip ? a.img_clip[b] : 0) * a.cb_stride);
+    const int g8 = lane >> 5;
+    // A fragment of k-step s, m-tile t: plane (p, hi) at slot 32 t + (lane & 31) + (2 s + g8) TJ; lo: + X_PLANE
+    const int aoff = (p * 2) * X_PLANE + ((lane & 31) + g8 * TJ) * 4;
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][j][r] = 0.f;
+
+    // the weights of ONE chunk: a wave requests those of its next multiplication right after the previous one -- waves
+    // 0-3 at the end of their MFMA phase (chunk c + 1), waves 4-7 at the start of the period (chunk c) -- and transforms
+    // while they arrive
+    // The loads are asm as well: left to the compiler, whose bookkeeping of what is in flight does not survive this
+    // loop's branches, they are followed by s_waitcnt vmcnt(0) in three places.  NOTHING may touch fb between the
+    // request and the s_waitcnt that opens the multiply block -- the compiler believes the values are there when the
+    // asm statement ends; tools/check_wino128_isa.py verifies that on the compiled kernel (run by the test-suite).
+    f32x4 fb[KH / 2][2][2];                  // [k-step][n-tile][hi|lo]
+    const unsigned ub_lo = (unsigned)(lane * 16), ub_hi = ub_lo + 4096u;     // byte offsets of k-step 0 / 1 within a chunk
+    const char* const ub_base = reinterpret_cast<const char*>(a.wino_u8 + ((size_t)(nb * 8 + p) * NC * (KH / 2)) * 1024);
+#define X_LOAD_B(CC)                                                                               \
+    {                                                                                              \
+        const int cc_ = (CC) < NC ? (CC) : NC - 1;                                                 \
+        const char* u_ = ub_base + (size_t)cc_ * (KH / 2) * 4096;                                  \
+        asm volatile(                                                                              \
+            "global_load_dwordx4 %0, %8, %10\n global_load_dwordx4 %1, %8, %10 offset:1024\n"      \
+            "global_load_dwordx4 %2, %8, %10 offset:2048\n global_load_dwordx4 %3, %8, %10 offset:3072\n" \
+            "global_load_dwordx4 %4, %9, %10\n global_load_dwordx4 %5, %9, %10 offset:1024\n"      \
+            "global_load_dwordx4 %6, %9, %10 offset:2048\n global_load_dwordx4 %7, %9, %10 offset:3072" \
+            : "=&v"(fb[0][0][0]), "=&v"(fb[0][0][1]), "=&v"(fb[0][1][0]), "=&v"(fb[0][1][1]),      \
+              "=&v"(fb[1][0][0]), "=&v"(fb[1][0][1]), "=&v"(fb[1][1][0]), "=&v"(fb[1][1][1])       \
+            : "v"(ub_lo), "v"(ub_hi), "s"(u_) : "memory");                                         \
+    }
+    // The chunk's 8 steps (k-step s, m-tile t) of 6 MFMAs each as ONE asm block (see X_TRANSFORM for why): the V
+    // fragments of step i + 2 are requested behind the first MFMA of step i (ring of three) -- one wave per SIMD
+    // multiplies at a time, so its own MFMAs must cover its LDS latency --; an accumulator tile is used by every other
+    // MFMA (a dependent MFMA issued back to back would wait for the first one's 8 passes).
+    // operands: 0-7 acc[t][j]; 8-13 ring r = (hi %8+2r, lo %9+2r); 14-21 fb[s][j][h]; 22 / 23 LDS address of k-step 0 / 1
+    const unsigned a_addr = (unsigned)(aoff * 4);
+#define X_MF(ACC, B, A) "v_mfma_f32_32x32x16_f16 %" #ACC ", %" #B ", %" #A ", %" #ACC "\n"
+    // step: wait for the ring slot, first MFMA, request the fragments of step i + 2, five MFMAs
+#define X_STEP(WAIT, A0, A1, HI, LO, B0H, B0L, B1H, B1L, NEXT)                                     \
+    "s_waitcnt lgkmcnt(" #WAIT ")\n" X_MF(A0, B0H, LO) NEXT X_MF(A1, B1H, LO) X_MF(A0, B0L, HI) X_MF(A1, B1L, HI) X_MF(A0, B0H, HI) X_MF(A1, B1H, HI)
+#define X_MULTIPLY(VB)                                                                             \
+    if (!(DBG && (a.wino_m >> 8 & 2))) {                                                           \
+        f32x4 r0h, r0l, r1h, r1l, r2h, r2l;                                                        \
+        const unsigned a0_ = a_addr + (unsigned)((VB) * X_VBUF * 4), a1_ = a0_ + (unsigned)(2 * TJ * 16); \
+        asm volatile(                                                                              \
+            "s_waitcnt vmcnt(4)\n"                  /* the weights (behind them: one tile's 4 DMA requests) */ \
+            "ds_read_b128 %8, %22\n ds_read_b128 %9, %22 offset:%24\n"                             \
+            "ds_read_b128 %10, %22 offset:512\n ds_read_b128 %11, %22 offset:512+%24\n"            \
+            X_STEP(2, 0, 1, 8, 9, 14, 15, 16, 17, "ds_read_b128 %12, %22 offset:1024\n ds_read_b128 %13, %22 offset:1024+%24\n") \
+            X_STEP(2, 2, 3, 10, 11, 14, 15, 16, 17, "ds_read_b128 %8, %22 offset:1536\n ds_read_b128 %9, %22 offset:1536+%24\n") \
+            X_STEP(2, 4, 5, 12, 13, 14, 15, 16, 17, "ds_read_b128 %10, %23\n ds_read_b128 %11, %23 offset:%24\n") \
+            X_STEP(2, 6, 7, 8, 9, 14, 15, 16, 17, "ds_read_b128 %12, %23 offset:512\n ds_read_b128 %13, %23 offset:512+%24\n") \
+            X_STEP(2, 0, 1, 10, 11, 18, 19, 20, 21, "ds_read_b128 %8, %23 offset:1024\n ds_read_b128 %9, %23 offset:1024+%24\n") \
+            X_STEP(2, 2, 3, 12, 13, 18, 19, 20, 21, "ds_read_b128 %10, %23 offset:1536\n ds_read_b128 %11, %23 offset:1536+%24\n") \
+            X_STEP(2, 4, 5, 8, 9, 18, 19, 20, 21, "")                                              \
+            X_STEP(0, 6, 7, 10, 11, 18, 19, 20, 21, "")                                            \
+            : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[1][0]), "+v"(acc[1][1]), "+v"(acc[2][0]), "+v"(acc[2][1]), "+v"(acc[3][0]), "+v"(acc[3][1]), \
+              "=&v"(r0h), "=&v"(r0l), "=&v"(r1h), "=&v"(r1l), "=&v"(r2h), "=&v"(r2l)               \
+            : "v"(fb[0][0][0]), "v"(fb[0][0][1]), "v"(fb[0][1][0]), "v"(fb[0][1][1]), "v"(fb[1][0][0]), "v"(fb[1][0][1]), "v"(fb[1][1][0]), "v"(fb[1][1][1]), \
+              "v"(a0_), "v"(a1_), "n"(X_PLANE * 4) : "memory");                                    \
+    }
+
+    // ---- prologue: tiles 0..2 and the weights of chunk 0 requested (tile 0 first: everybody waits for it), V of
+    // chunk 0 transformed by all eight waves ----
+    X_DMA(0, 0)
+    __builtin_amdgcn_sched_barrier(0);
+    if (early) X_LOAD_B(0)
+    __builtin_amdgcn_sched_barrier(0);
+    X_DMA(1, 1)
+    X_DMA(2, 2)
+    long long dbg_setup = 0;
+    if constexpr (DBG) dbg_setup = (long long)__builtin_amdgcn_s_memtime() - dbg_entry;
+    // tile 0 (behind it: 8 weight loads in waves 0-3, 2 x 4 DMA)
+    if (early) asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    long long dbg_landed = 0;
+    if constexpr (DBG) dbg_landed = (long long)__builtin_amdgcn_s_memtime() - dbg_entry;
+    X_TRANSFORM(0, 0)
+    asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");         // tile 1
+    __builtin_amdgcn_s_barrier();
+
+    // ---- K loop.  Period c (between two barriers): every wave multiplies chunk c, transforms its share of chunk
+    // c + 1 (from the tile that landed a period ago) and requests the weights of chunk c + 1 and the tile of chunk
+    // c + 3.  In flight at the end of a period, in order: tile c+2 (4) | weights (8) | tile c+3 (4): vmcnt(12) says
+    // tile c+2 has landed. ----
+    long long dbg_t0 = 0, dbg_bar = 0, dbg_t1 = 0;
+    if constexpr (DBG) dbg_t0 = (long long)__builtin_amdgcn_s_memtime();
+    int rb3 = 0;                                   // c % 3
+#define X_PERIOD(C_, VB)                                                                           \
+    {                                                                                              \
+        const int c_ = (C_);                                                                       \
+        const int rn_ = rb3 == 2 ? 0 : rb3 + 1;                /* (c + 1) % 3 */                    \
+        if (early) X_MULTIPLY(VB)                                                                  \
+        __builtin_amdgcn_sched_barrier(0);                                                         \
+        X_LOAD_B(early ? c_ + 1 : c_)                                                              \
+        __builtin_amdgcn_sched_barrier(0);                                                         \
+        X_DMA(c_ + 3, rb3)                                                                         \
+        __builtin_amdgcn_sched_barrier(0);                                                         \
+        if (c_ + 1 < NC && !(DBG && (a.wino_m >> 8 & 4))) {                                        \
+            __builtin_amdgcn_s_setprio(2);                                                         \
+            X_TRANSFORM(rn_, VB ^ 1)                                                               \
+            __builtin_amdgcn_s_setprio(0);                                                         \
+        }                                                                                          \
+        __builtin_amdgcn_sched_barrier(0);                                                         \
+        if (!early) X_MULTIPLY(VB)                                                                 \
+        asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)" ::: "memory");                               \
+        long long tq_ = 0;                                                                         \
+        if constexpr (DBG) tq_ = (long long)__builtin_amdgcn_s_memtime();                          \
+        __builtin_amdgcn_s_barrier();                                                              \
+        if constexpr (DBG) dbg_bar += (long long)__builtin_amdgcn_s_memtime() - tq_;               \
+        rb3 = rn_;                                                                                 \
+    }
+#pragma unroll 1
+    for (int c = 0; c < NC; c += 2) {
+        X_PERIOD(c, 0)
+        X_PERIOD(c + 1, 1)
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                    // (the tail's dummy requests: nothing may land in LDS later)
+    if constexpr (DBG) dbg_t1 = (long long)__builtin_amdgcn_s_memtime();
+#undef X_PERIOD
+#undef X_MULTIPLY
+#undef X_STEP
+#undef X_MF
+#undef X_LOAD_B
+#undef X_TRANSFORM
+#undef X_BT
+#undef X_DMA
+
+    // ---- epilogue in two passes of 64 tile-pixels (the eight M_p tiles of a pass are 136 KB of LDS) ----
+    long long es[3] = {0, 0, 0};
+#define X_EPI(IDM)                                                                                 \
+    {                                                                                              \
+        wino_epilogue<IDM, MO>(a, acc, smem, p, lane, tid, b, nb, r0, j0, TR, TJ, cbx, DBG ? es : nullptr, 0, true); \
+        __builtin_amdgcn_s_barrier();                                                              \
+        wino_epilogue<IDM, MO>(a, acc + 2, smem, p, lane, tid, b, nb, r0, j0, TR, TJ, cbx, nullptr, 64, false); \
+    }
+    switch (a.id_mode) {
+        case 0: X_EPI(0) break;
+        case 1:
+            if (a.id_split) X_EPI(1) else X_EPI(2)
+            break;
+        default: X_EPI(3) break;
+    }
+#undef X_EPI
+    if constexpr (DBG) {                                                // [K loop, prologue, epilogue, barrier waits in the loop]
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (a.dbg && lane == 0) {
+            const long long t_end = (long long)__builtin_amdgcn_s_memtime();
+            long long* d = a.dbg + ((size_t)blockIdx.x * 12 + wave) * 4;
+            d[0] = dbg_t1 - dbg_t0; d[1] = dbg_t0 - dbg_entry; d[2] = t_end - dbg_t1; d[3] = dbg_bar;
+            long long* e = a.dbg + (size_t)(4 << 20) + ((size_t)blockIdx.x * 12 + wave) * 8;
+            e[0] = dbg_setup; e[1] = dbg_landed; e[2] = es[0] - dbg_t1; e[3] = es[1] - dbg_t1; e[4] = es[2] - dbg_t1; e[5] = t_end - dbg_t1;
+        }
+    }
+}
+
+namespace {
+// tile-pixel block (rows x tiles, <= 128) for an Ho x ntile grid: the largest useful fraction of the 128-slot blocks,
+// subject to the staged tile, the slots of a V plane and one transform task per thread
+void wino128_block(int Ho, int ntile, int KH, int m, int* tr, int* tj) {
+    double best = -1;
+    for (int r = 1; r <= 128; ++r)
+        for (int t = 1; r * t <= 128; ++t) {
+            if (r + KH - 1 > X_RROWS || t * m + KH - 1 > X_RPX) continue;                            // staged tile
+            if (128 + (KH - 1) * t > X_NSLOT || (r + KH - 1) * t * 2 > XW * 64) continue;            // V slots, transform tasks
+            const int nrb = (Ho + r - 1) / r, ncb = (ntile + t - 1) / t;
+            // useful fraction of the MFMA work, discounted by the rows transformed per output row
+            const double u = (double)Ho * ntile / ((double)nrb * ncb * 128) - 0.02 * (double)(r + KH - 1) / r;
+            if (u > best) { best = u; *tr = r; *tj = t; }
+        }
+}
+
+template <int KH, int MO, int DBG = 0> void launch_wino128_t(const ConvArgs& a, hipStream_t s) {
+    static unsigned long long attr_devices = 0;
+    set_max_dynamic_lds(reinterpret_cast<const void*>(&conv_wino128<KH, MO, DBG>), kWino128Lds, &attr_devices, "conv_wino128");
+    const int frames = a.M / (a.Ho * a.Wo);
+    const int grid = frames * a.wino_nrb * a.wino_ncb * (a.N / 64);
+    NHANS_LAUNCH("conv_wino128", (conv_wino128<KH, MO, DBG>), dim3(grid), dim3(XW * 64), kWino128Lds, s, a);
+}
+
+void wino128_geometry(ConvArgs& a) {
+    const ConvSeg& g = a.seg[0];
+    a.wino_m = 9 - g.KW;                                               // 8 positions: 5 outputs for 4 taps
+    a.wino_ntile = (a.Wo + a.wino_m - 1) / a.wino_m;
+    wino128_block(a.Ho, a.wino_ntile, g.KH, a.wino_m, &a.wino_tr, &a.wino_tj);
+    a.wino_nrb = (a.Ho + a.wino_tr - 1) / a.wino_tr;
+    a.wino_ncb = (a.wino_ntile + a.wino_tj - 1) / a.wino_tj;
+    a.wino_fd_nnb = make_fastdiv((uint32_t)(a.N / 64));
+    a.wino_fd_ncb = make_fastdiv((uint32_t)a.wino_ncb);
+    a.wino_fd_bpf = make_fastdiv((uint32_t)(a.wino_nrb * a.wino_ncb * (a.N / 64)));
+}
+}  // namespace
+
+bool conv_wino128_eligible(const ConvArgs& a) {
+    return a.wino >= 2 && a.wino_u8 && conv_wino_shape_ok(a);
+}
+
+// MFMA FLOPs of the launch: every workgroup multiplies 8 positions x 128 tile-pixel slots (used or not) x 64
+// channels over K = KH * C, three split-f16 products per MAC
+double conv_wino128_mfma_flops(const ConvArgs& a0) {
+    ConvArgs a = a0;
+    wino128_geometry(a);
+    const double wgs = (double)(a.M / (a.Ho * a.Wo)) * a.wino_nrb * a.wino_ncb * (a.N / 64);
+    return wgs * 8.0 * 128.0 * 64.0 * (double)(a.seg[0].KH * a.seg[0].C) * 2.0 * 3.0;
+}
+
+void launch_conv_wino128(const ConvArgs& a0, hipStream_t s) {
+    ConvArgs a = a0;
+    wino128_geometry(a);
+    a.ws = a.wino_ws;
+#ifdef NHANS_DEV
+    // NHANS_ABLATE (timing experiments, wrong results): 1 input tiles of chunks >= 1 from the zero page, 2 no MFMAs,
+    // 4 no transforms after the first chunk, 8 residual from one L2-hot line and no stores
+    if (a.dbg) { a.wino_m |= (dev_ablate() & 31) << 8; launch_wino128_t<4, 5, 1>(a, s); return; }
+#endif
+    launch_wino128_t<4, 5>(a, s);
+}
+
+}  // namespace nhans

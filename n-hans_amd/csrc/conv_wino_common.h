@@ -1,0 +1,268 @@
+// Shared by the Winograd conv kernels (conv_wino.hip, conv_wino128.hip): the split / un-split helpers, the layout
+// constant of the exchanged accumulator tiles and the fused output-transform + block epilogue of a 512-thread
+// consumer group (one pass = 64 tile-pixels x 64 channels x 8 positions through LDS).
+#pragma once
+#include "conv_epilogue.h"
+#include <cstddef>
+
+#include <algorithm>
+
+namespace nhans {
+
+namespace {
+constexpr int W_LDM = 68;                      // epilogue: floats per tile-pixel row of an M_p tile (64 + 4)
+// LDS of one epilogue pass: eight M_p tiles of 64 tile-pixels + the block's constants (ws, idw, one bias row per block row)
+constexpr size_t kWinoLdsEpi = (size_t)(8 * 64 * W_LDM + (2 + 64) * 64) * sizeof(float);
+
+// split of two f32 values into packed f16 pairs: hi = RNE(v) (one v_cvt_pk_f16_f32), lo = RNE(v - hi) as one
+// v_fma_mixlo_f16 / v_fma_mixhi_f16 each (f16 source, f32 addend, f16 result into one half of the destination)
+__device__ __forceinline__ void split_pair(float vx, float vy, unsigned* hi, unsigned* lo) {
+    typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
+    const h2_t h = {(_Float16)vx, (_Float16)vy};
+    const unsigned hb = __builtin_bit_cast(unsigned, h);
+    unsigned l;
+    asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(l) : "v"(hb), "v"(vx));
+    asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(l) : "v"(hb), "v"(vy));
+    *hi = hb;
+    *lo = l;
+}
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ f16x8 as_h8(f32x4 v) { return __builtin_bit_cast(f16x8, v); }
+
+// value of a split-f16 element: (float)hi.half[SEL] + (float)lo.half[SEL] in ONE instruction (v_fma_mix_f32 reads
+// f16 halves of 32-bit registers as sources of an f32 fma; the compiler spends two conversions and an add on it)
+template <int SEL> __device__ __forceinline__ float unsplit_mix(float hi_pair, float lo_pair) {
+    float d;
+    if constexpr (SEL == 0) asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,1]" : "=v"(d) : "v"(hi_pair), "v"(lo_pair));
+    else asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[1,0,1] op_sel_hi:[1,0,1]" : "=v"(d) : "v"(hi_pair), "v"(lo_pair));
+    return d;
+}
+}  // namespace
+
+// Epilogue of a consumer thread: the wave's accumulator tiles M_p go to LDS, then the thread = (tile-pixel q, 8
+// channels) forms its MO output columns and runs the fused block epilogue on them.
+//   * `ct` holds the eight transformed-domain tiles M_p[64 tile-pixels][W_LDM] (channel 8a + 4b + c of a row at float
+//     b*32 + a*4 + c: the eight threads of a tile-pixel read 128 contiguous bytes at a time).  The thread reads its
+//     8 x 8 values ONCE and forms all MO columns Y_i = sum_p AT[i][p] M_p with the shared sums of the +-1, +-2, +-1/2
+//     point pairs (18 instead of 8*MO operations per channel), two channels at a time, and applies the first step of
+//     the block epilogue, fma(y, ws, bias), on the spot.
+//   * The MO columns of a tile-pixel are MO consecutive pixels of one image row of ONE frame: every address is a
+//     uniform frame base (scalar registers) + one 32-bit offset + a column stride, instead of a 64-bit pointer and a
+//     row-info record per column.  A column past the image's right edge (or a slot outside the block) loads from the
+//     thread's last valid pixel and is not stored.
+//   * The residual -- HBM, ~2,000 cycles away -- of ALL columns is requested BEFORE the accumulators go to LDS: the
+//     exchange, the barrier and the output transform run under that latency.  The position table (L2) follows one
+//     column ahead of its use.  Everything up to the two stores of a column is unconditional: with the arithmetic
+//     inside `if (valid)` the compiler sinks the (restrict) table loads into the branch, right in front of their use,
+//     with s_waitcnt vmcnt(0) -- one full memory latency per column, 2,750 cycles each, was what round 3's first
+//     version of this sweep spent.
+// IDM: 0 no residual, 1 split-NHWC tensor, 2 f32 NHWC tensor, 3 one-channel image.
+template <int IDM, int MO>
+__device__ __forceinline__ void wino_epilogue(const ConvArgs& a, const f32x16 (*acc)[2], float* ct, int p, int lane, int tid,
+                                              int b, int nb, int r0, int j0, int TR, int TJ, int cx, long long* es,
+                                              int qbase = 0, bool first = true) {
+    const int g8 = lane >> 5;
+    const int c8 = tid & 7, q = tid >> 3;
+    const int n = nb * 64 + c8 * 8;
+    const int rr = (q + qbase) / TJ, tt = q + qbase - rr * TJ;
+    const int ho = r0 + rr, wo0 = (j0 + tt) * MO;
+    const bool okq = rr < TR && ho < a.Ho && j0 + tt < a.wino_ntile;
+    const int nvalid = okq ? (a.Wo - wo0 < MO ? a.Wo - wo0 : MO) : 0;       // columns of this tile-pixel inside the image
+    const int pix0 = okq ? ho * a.Wo + wo0 : 0;                                // first pixel, within the frame
+    const int lastc = nvalid > 0 ? nvalid - 1 : 0;
+    const int hoff = (n >> 5) * 64 + (n & 31);                                // half index inside a split-NHWC pixel
+    const size_t fpix = (size_t)b * a.Ho * a.Wo;                              // uniform
+    // position table = tt[ho] + ff[wo] (two small arrays: the [Ho*Wo, N] table of these layers, 1.8 MB, did not survive
+    // in L2 and came from HBM again almost once per frame).  An absent table reads the zero page.
+    const int f_tf = a.tt ? 1 : 0;
+    const char* const ffb = reinterpret_cast<const char*>(a.tt ? a.ff : a.zero);
+    const float lo_clamp = a.relu ? 0.f : -3.0e38f;
+
+    // 0. the per-channel constants (ws, bias, idw of the block's 64 channels), fetched by the eight threads of
+    // tile-pixel 0 BEFORE the residual requests -- loads return in order, so a constant fetched after them could not be
+    // used until every residual has arrived -- and handed to everybody through LDS with the accumulator tiles
+    // cst: [ws | idw][64], then per block row r: bias + tt[r0 + r] (the time term of the position table rides in the bias
+    // of the transform stage: v = fma(y, ws, bias + tt) + ff), fetched by the first tile-pixel of each row
+    float* const cst = ct + 8 * 64 * W_LDM;
+    f32x4 ka[4], kb[4];
+    const bool row_head = tt == 0 && rr < TR;
+    const bool chan_head = q == 0 && first;
+    if (chan_head) {
+        ka[0] = *reinterpret_cast<const f32x4*>(a.ws + n); ka[1] = *reinterpret_cast<const f32x4*>(a.ws + n + 4);
+        if constexpr (IDM != 0) { ka[2] = *reinterpret_cast<const f32x4*>(a.idw + n); ka[3] = *reinterpret_cast<const f32x4*>(a.idw + n + 4); }
+    }
+    if (row_head) {
+        const float* ttp = a.tt ? a.tt + (size_t)(ho < a.Ho ? ho : 0) * a.N + n : a.zero;
+        kb[0] = *reinterpret_cast<const f32x4*>(a.cb + cx + n); kb[1] = *reinterpret_cast<const f32x4*>(a.cb + cx + n + 4);
+        kb[2] = *reinterpret_cast<const f32x4*>(ttp); kb[3] = *reinterpret_cast<const f32x4*>(ttp + 4 * f_tf);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+
+    // 1. residual requests of all columns
+    f32x4 rh[MO], rl[MO];
+    float rsv[MO];
+    if constexpr (IDM == 1) {
+        const char* const idb = reinterpret_cast<const char*>(a.id + fpix * a.id_ld);
+        const uint32_t o0 = (uint32_t)pix0 * (uint32_t)a.id_ld * 4u + (uint32_t)hoff * 2u, st = (uint32_t)a.id_ld * 4u;
+#pragma unroll
+        for (int i = 0; i < MO; ++i) {
+            const uint32_t o = (kDev && (a.wino_m >> 8 & 8)) ? (uint32_t)hoff * 2u : o0 + (uint32_t)(i < lastc ? i : lastc) * st;
+            // non-temporal: the residual is read once and the output written once -- left at the default policy these
+            // streams pushed the input tiles' halo rows (and the weights) out of the 4 MB L2 before the neighbouring
+            // workgroup came for them: with the hint the 64-channel layers' HBM reads equal their algorithmic bytes
+            rh[i] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(idb + o));
+            rl[i] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(idb + o + 64));
+        }
+    } else if constexpr (IDM == 2) {
+        const char* const idb = reinterpret_cast<const char*>(a.id + fpix * a.id_ld);
+        const uint32_t o0 = ((uint32_t)pix0 * (uint32_t)a.id_ld + (uint32_t)n) * 4u, st = (uint32_t)a.id_ld * 4u;
+#pragma unroll
+        for (int i = 0; i < MO; ++i) {
+            const uint32_t o = o0 + (uint32_t)(i < lastc ? i : lastc) * st;
+            rh[i] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(idb + o));
+            rl[i] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(idb + o + 16));
+        }
+    } else if constexpr (IDM == 3) {
+        const int ids0 = (b * a.idH + (okq ? ho : 0) * a.idsh) * a.idW + (okq ? wo0 : 0) * a.idsw;
+#pragma unroll
+        for (int i = 0; i < MO; ++i) rsv[i] = a.id[ids0 + (i < lastc ? i : lastc) * a.idsw];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+
+    // 2. accumulators -> LDS.  Channel n = 8a + 4b + c of the 64 sits at float b*32 + a*4 + c of its row: the sweep
+    // thread of channel group a reads two 16-byte pieces, and eight such threads cover 128 contiguous bytes each time
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) {
+                const f32x4 v = {acc[t][j][4 * q4], acc[t][j][4 * q4 + 1], acc[t][j][4 * q4 + 2], acc[t][j][4 * q4 + 3]};
+                *reinterpret_cast<f32x4*>(ct + (p * 64 + t * 32 + (lane & 31)) * W_LDM + g8 * 32 + (j * 4 + q4) * 4) = v;
+            }
+    if (chan_head) {
+        const float in_scale = CONV_KARG(in_scale), id_scale = CONV_KARG(id_scale);
+        *reinterpret_cast<f32x4*>(cst + c8 * 8) = ka[0] * in_scale; *reinterpret_cast<f32x4*>(cst + c8 * 8 + 4) = ka[1] * in_scale;
+        if constexpr (IDM != 0) {
+            *reinterpret_cast<f32x4*>(cst + 64 + c8 * 8) = ka[2] * id_scale; *reinterpret_cast<f32x4*>(cst + 64 + c8 * 8 + 4) = ka[3] * id_scale;
+        }
+    }
+    if (row_head) {
+        *reinterpret_cast<f32x4*>(cst + (2 + rr) * 64 + c8 * 8) = kb[0] + kb[2];
+        *reinterpret_cast<f32x4*>(cst + (2 + rr) * 64 + c8 * 8 + 4) = kb[1] + kb[3];
+    }
+    if (kDev && es) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); es[0] = (long long)__builtin_amdgcn_s_memtime(); }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                              // (raw: the residual loads stay in flight across it)
+    if (kDev && es) es[1] = (long long)__builtin_amdgcn_s_memtime();
+
+    // 3. output transform, two channels at a time (8 x 8-byte LDS reads), with fma(y, ws, bias) -- the first step of
+    // the block epilogue -- applied on the spot.  The MO results go straight BACK to LDS, into the slots of positions
+    // 0 .. MO-1 the thread has just read (nobody else touches the slots of its tile-pixel and channels): the column loop
+    // below then holds one column of outputs instead of MO, which is what lets the residual of all columns stay in
+    // registers.  (Stored tensors carry 2^-e: ConvArgs::in_scale / id_scale / out_scale.)
+    // the position table (L2): the first TAHEAD columns ahead of the transform, then TAHEAD columns ahead of their use
+    // (all MO at once do not fit the register file beside the residuals)
+    const uint32_t to0 = ((uint32_t)(okq ? wo0 : 0) * (uint32_t)a.N + (uint32_t)n) * 4u * f_tf, tst = (uint32_t)a.N * 4u * f_tf;
+    f32x4 t0[MO], t1[MO];
+    auto table = [&](int i) {
+        const uint32_t o = to0 + (uint32_t)(i < lastc ? i : lastc) * tst;
+        t0[i] = *reinterpret_cast<const f32x4*>(ffb + o);
+        t1[i] = *reinterpret_cast<const f32x4*>(ffb + o + 16 * f_tf);
+    };
+    constexpr int TAHEAD = 2;
+#pragma unroll
+    for (int i = 0; i < TAHEAD; ++i) table(i);
+    __builtin_amdgcn_sched_barrier(0);
+    float* const my = ct + q * W_LDM + c8 * 4;                                // + position * 64 * W_LDM + (0 | 32)
+#pragma unroll
+    for (int qt = 0; qt < 4; ++qt) {
+        float* const slot = my + (qt >> 1) * 32 + (qt & 1) * 2;
+        f32x2 m[8];
+#pragma unroll
+        for (int pp = 0; pp < 8; ++pp) m[pp] = *reinterpret_cast<const f32x2*>(slot + pp * 64 * W_LDM);
+        const f32x2 ws2 = *reinterpret_cast<const f32x2*>(cst + c8 * 8 + 2 * qt);
+        const f32x2 hc2 = *reinterpret_cast<const f32x2*>(cst + (2 + (rr < TR ? rr : 0)) * 64 + c8 * 8 + 2 * qt);
+        const f32x2 s12 = m[1] + m[2], d12 = m[1] - m[2], s34 = m[3] + m[4], d34 = m[3] - m[4], s56 = m[5] + m[6], d56 = m[5] - m[6];
+        f32x2 y[MO];
+        y[0] = (m[0] + s12) + (s34 + s56);
+        y[1] = d12 + 2.f * d34 + 0.5f * d56;
+        y[2] = s12 + 4.f * s34 + 0.25f * s56;
+        y[3] = d12 + 8.f * d34 + 0.125f * d56;
+        if constexpr (MO == 5) {
+            y[4] = (s12 + m[7]) + 16.f * s34 + 0.0625f * s56;
+        } else {
+            y[4] = s12 + 16.f * s34 + 0.0625f * s56;
+            y[MO - 1] = (d12 + m[7]) + 32.f * d34 + 0.03125f * d56;
+        }
+#pragma unroll
+        for (int i = 0; i < MO; ++i)
+            *reinterpret_cast<f32x2*>(slot + i * 64 * W_LDM) =
+                f32x2{__builtin_fmaf(y[i].x, ws2.x, hc2.x), __builtin_fmaf(y[i].y, ws2.y, hc2.y)};
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    if (kDev && es) es[2] = (long long)__builtin_amdgcn_s_memtime();
+
+    // 4. columns
+    f32x4 iw0 = {0.f, 0.f, 0.f, 0.f}, iw1 = iw0;
+    if constexpr (IDM != 0) {
+        iw0 = *reinterpret_cast<const f32x4*>(cst + 64 + c8 * 8);
+        iw1 = *reinterpret_cast<const f32x4*>(cst + 64 + c8 * 8 + 4);
+    }
+    const float osc = CONV_KARG(out_scale), slim = CONV_KARG(sat_limit);
+    char* const outb = reinterpret_cast<char*>(a.out + fpix * a.ldo);
+    int n_again = n;                                           // (recomputed, not kept: one register fewer across the transform)
+    asm volatile("" : "+v"(n_again));
+    const uint32_t oo0 = (uint32_t)pix0 * (uint32_t)a.ldo * 4u + (uint32_t)((n_again >> 5) * 64 + (n_again & 31)) * 2u, ost = (uint32_t)a.ldo * 4u;
+    int sat = 0;
+#pragma unroll
+    for (int i = 0; i < MO; ++i) {
+        if (i + TAHEAD < MO) table(i + TAHEAD);
+        const f32x4 ya = *reinterpret_cast<const f32x4*>(my + i * 64 * W_LDM);
+        const f32x4 yb = *reinterpret_cast<const f32x4*>(my + i * 64 * W_LDM + 32);
+        f32x4 i0 = {0.f, 0.f, 0.f, 0.f}, i1 = i0;
+        if constexpr (IDM == 1) {
+            // (float)hi + (float)lo, one v_fma_mix_f32 per value
+            i0 = f32x4{unsplit_mix<0>(rh[i].x, rl[i].x), unsplit_mix<1>(rh[i].x, rl[i].x), unsplit_mix<0>(rh[i].y, rl[i].y), unsplit_mix<1>(rh[i].y, rl[i].y)};
+            i1 = f32x4{unsplit_mix<0>(rh[i].z, rl[i].z), unsplit_mix<1>(rh[i].z, rl[i].z), unsplit_mix<0>(rh[i].w, rl[i].w), unsplit_mix<1>(rh[i].w, rl[i].w)};
+        } else if constexpr (IDM == 2) {
+            i0 = rh[i];
+            i1 = rl[i];
+        } else if constexpr (IDM == 3) {
+            i0 = f32x4{rsv[i], rsv[i], rsv[i], rsv[i]};
+            i1 = i0;
+        }
+        const f32x4 r0v = fma4(iw0, i0, ya + t0[i]);           // (= epi_combine: ya already is fma(acc, ws, bias))
+        const f32x4 r1v = fma4(iw1, i1, yb + t1[i]);
+        const bool valid = i < nvalid;
+        float yc[8];
+        bool over = false;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float v = fmaxf(e < 4 ? r0v[e] : r1v[e - 4], lo_clamp) * osc;
+            over |= !(fabsf(v) < slim);
+            yc[e] = __builtin_amdgcn_fmed3f(v, -65504.f, 65504.f);
+        }
+        sat |= (over && valid) ? 1 : 0;
+        asm volatile("" : "+v"(sat));                       // (here, not after the loop: the compiler would keep all 8*MO values alive for it)
+        uint4 hb, lb;
+        split_pair(yc[0], yc[1], &hb.x, &lb.x);
+        split_pair(yc[2], yc[3], &hb.y, &lb.y);
+        split_pair(yc[4], yc[5], &hb.z, &lb.z);
+        split_pair(yc[6], yc[7], &hb.w, &lb.w);
+        if (valid && !(kDev && (a.wino_m >> 8 & 8))) {
+            char* dst = outb + (oo0 + (uint32_t)i * ost);
+            typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+            __builtin_nontemporal_store(u32x4{hb.x, hb.y, hb.z, hb.w}, reinterpret_cast<u32x4*>(dst));   // (written once, read by the next launch)
+            __builtin_nontemporal_store(u32x4{lb.x, lb.y, lb.z, lb.w}, reinterpret_cast<u32x4*>(dst + 64));
+        }
+        __builtin_amdgcn_sched_barrier(0);                     // (column by column: bounded register pressure)
+    }
+    int* const satp = CONV_KARG(sat);
+    if (sat && satp) atomicOr(satp, kSatActivation);
+}
+
+}  // namespace nhans

@@ -256,7 +256,7 @@ void fill_epilogue_defaults(nhans_ctx* c, ConvArgs& a) {
     a.ilv = c->ilv;
     a.persist = c->persist;
     a.quad = c->quad;
-    a.wino = c->wino; a.wino_u = nullptr; a.wino_ws = nullptr;
+    a.wino = c->wino; a.wino_u = nullptr; a.wino_u8 = nullptr; a.wino_ws = nullptr;
     a.kscratch = c->kscratch; a.kscratch_bytes = c->kscratch_bytes; a.kcounter = c->kcounter; a.kcounter_n = c->kcounter_n; a.kgroup = 0;
 }
 
@@ -453,7 +453,7 @@ float* run_stack_chunk(nhans_ctx* c, const float* logmag, const StackBufs& sb, i
             a.cb = cb1; a.cb_stride = c->cond_cols; a.img_clip = clipmap;
             a.tf = c->A(p + ".c1.tf"); a.tt = c->A(p + ".c1.tt"); a.ff = c->A(p + ".c1.ff");
             a.ws = c->WS(p + ".c1");
-            a.wino_u = c->A(p + ".c1.wino"); a.wino_ws = c->A(p + ".c1.wino.ws");
+            a.wino_u = c->A(p + ".c1.wino"); a.wino_u8 = c->A(p + ".c1.wino8"); a.wino_ws = c->A(p + ".c1.wino.ws");
             a.in_scale = c->up(SA(b - 1, 1)); a.out_scale = c->down(SA(b, 0));
             a.sat_limit = sat_limit_for(c, b, 2);
             run_conv(c, a, s);
@@ -467,7 +467,7 @@ float* run_stack_chunk(nhans_ctx* c, const float* logmag, const StackBufs& sb, i
         a.tf = c->A(p + ".c2.tf"); a.tt = c->A(p + ".c2.tt"); a.ff = c->A(p + ".c2.ff");
         a.idw = c->A(p + ".c2.idw");
         a.ws = c->WS(p + ".c2");
-        a.wino_u = c->A(p + ".c2.wino"); a.wino_ws = c->A(p + ".c2.wino.ws");
+        a.wino_u = c->A(p + ".c2.wino"); a.wino_u8 = c->A(p + ".c2.wino8"); a.wino_ws = c->A(p + ".c2.wino.ws");
         a.in_scale = c->up(SA(b, 0)); a.out_scale = c->down(SA(b, 1));
         a.sat_limit = sat_limit_for(c, b + 1, 1);
         float* out;
@@ -935,7 +935,10 @@ int nhans_set_option(nhans_ctx* c, const char* key, int64_t value) {
             return finish_calibration(c, value == 2);
         }
     }
-    else if (k == "winograd") c->wino = value != 0;
+    else if (k == "winograd") {
+        if (value < 0 || value > 2) return fail(NHANS_EINVAL, "winograd must be 0 (off), 1 (64 tile-pixels per weight fragment) or 2 (128)");
+        c->wino = (int)value;
+    }
     else if (k == "ab_build") return kAB ? NHANS_OK : fail(NHANS_EINVAL, "not an AB=1 build");   // query: 0 = yes
     else if (k == "precision") {
         if (value != 0 && value != 1) return fail(NHANS_EINVAL, "precision must be 0 (f32) or 1 (f16x3)");

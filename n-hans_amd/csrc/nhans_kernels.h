@@ -155,9 +155,10 @@ struct ConvArgs {
     // 1-D Winograd along W (conv_wino.hip).  Caller: wino_u / wino_ws (null = this conv has no Winograd form) and
     // wino on/off; the launcher fills in the rest: outputs per tile, tile-pixel block (rows x tiles, <= 64), blocks
     // per frame, tiles per image row
-    const float* wino_u;
+    const float* wino_u;   // conv_wino.hip's pack (16-channel chunks)
+    const float* wino_u8;  // conv_wino128.hip's pack (8-channel chunks, two filter rows per k-step)
     const float* wino_ws;
-    int wino;
+    int wino;              // 0 off, 1 conv_wino.hip (M = 64 tile-pixels per weight fragment), 2 conv_wino128.hip where its pack exists
     int wino_m, wino_tr, wino_tj, wino_nrb, wino_ncb, wino_ntile;
     FastDiv wino_fd_bpf, wino_fd_nnb, wino_fd_ncb;   // blocks per frame, channel blocks, column blocks (block decode)
     // 2-D pixel tiles (conv_igemm_halo2d.hip; filled in by its launcher): th x tw output pixels of one
@@ -172,7 +173,11 @@ double launch_conv_igemm(const ConvArgs& a, hipStream_t s, const char** kernel =
 double conv_wino_mfma_flops(const ConvArgs& a);                 // conv_wino.hip
 void launch_conv_igemm_dma(const ConvArgs& a, hipStream_t s);   // conv_igemm_dma.hip
 bool conv_wino_eligible(const ConvArgs& a);                     // conv_wino.hip
+bool conv_wino_shape_ok(const ConvArgs& a);
 void launch_conv_wino(const ConvArgs& a, hipStream_t s);
+bool conv_wino128_eligible(const ConvArgs& a);                  // conv_wino128.hip
+void launch_conv_wino128(const ConvArgs& a, hipStream_t s);
+double conv_wino128_mfma_flops(const ConvArgs& a);
 bool conv_igemm_halo_eligible(const ConvArgs& a);               // conv_igemm_halo.hip
 void launch_conv_igemm_halo(const ConvArgs& a, hipStream_t s);
 bool conv_igemm_halo_pw_eligible(const ConvArgs& a);            // the same pipeline without halo reuse (strided / VALID convs)

@@ -207,6 +207,27 @@ def pack_wino(w4):
     return np.ascontiguousarray(pk).reshape(-1).view(np.float32), 1.0 / sc
 
 
+def pack_wino8(w4):
+    """The same transformed filter for conv_wino128.hip, whose MFMA k-step is 8 channels x TWO filter rows:
+    [N/64][p 8][C/8][s KH/2][nt 2][h 2][lane 64][e 8] -- lane l, element e of k-step s of 8-channel chunk c8 holds
+    filter row 2 s + (l >> 5), channel 8 c8 + e, column 64 nb + 32 nt + (l & 31).  Same values, scale and split as
+    pack_wino (the per-channel unscale vector is shared)."""
+    kh, kw, c, n = w4.shape
+    assert c % 16 == 0 and n % 64 == 0 and kh % 2 == 0
+    _, G, _ = wino_matrices(wino_outputs(kw), kw)
+    U = np.einsum("pk,hkcn->phcn", G, w4.astype(F64))              # [8, KH, C, N]
+    sc = col_scale(np.abs(U).reshape(-1, n))
+    Us = U * sc
+    hi = Us.astype(np.float16)
+    lo = (Us - hi.astype(F64)).astype(np.float16)
+    parts = []
+    for a in (hi, lo):
+        a = a.reshape(WINO_N, kh // 2, 2, c // 8, 8, n // 64, 2, 32)  # p, s, g8, c8, e, nb, nt, col
+        parts.append(a.transpose(5, 0, 3, 1, 6, 2, 7, 4))            # nb, p, c8, s, nt, g8, col, e
+    pk = np.stack(parts, axis=5)                                     # nb, p, c8, s, nt, h, g8, col, e
+    return np.ascontiguousarray(pk).reshape(-1).view(np.float32)
+
+
 def _pad(v, npad):
     o = np.ones(npad, dtype=F64)
     o[:len(v)] = v
@@ -295,6 +316,7 @@ def fold_arrays(W, kind, split_f16=True):
                 w4 = w64("%s_conv%d/w" % (s, cv)) * scl
                 if cin_ == c and wino_eligible(g["kh"], g["kw"], st[0], st[1], cin_, c):
                     out["%s.c%d.wino" % (p, cv)], out["%s.c%d.wino.ws" % (p, cv)] = pack_wino(w4)
+                    out["%s.c%d.wino8" % (p, cv)] = pack_wino8(w4)
         for cv, sc, sh, bias in ((1, s1, h1, 0.0), (2, sa, ha, extra_bias)):
             q = "%s_conv%d" % (s, cv)
             # time + frequency position terms in one [Ho*Wo, C] table (one coalesced read per output)

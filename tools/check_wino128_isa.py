@@ -1,0 +1,182 @@
+"""Build-time check of conv_wino128.hip's hand-counted waits (run by tests/test_host.py; needs hipcc only).
+
+The kernel requests its transformed weights with `global_load_dwordx4` inside inline asm and waits for them with the
+`s_waitcnt vmcnt(4)` that opens the multiply asm block.  The compiler believes the asm outputs are valid as soon as the
+request has been issued, so any instruction IT places between the two that reads or writes those registers -- a copy
+from live-range splitting, a spill, a reuse -- would see or destroy data that has not arrived.  This script compiles
+the file to gfx950 assembly and checks, for every instantiation of the kernel:
+  * the kernel has no scratch (no spills);
+  * every weight-request block writes 32 VGPRs, the multiply blocks that follow it in program order (one or two, the
+    loop taken round once) read exactly those as their weight operands, and no instruction outside the request /
+    multiply asm blocks mentions one of them in between;
+  * the K loop contains no compiler-generated `s_waitcnt vmcnt` (all of them come from the source) and no LDS
+    instruction outside inline asm.
+Exit code 0 = all good."""
+import os
+import re
+import subprocess
+import sys
+import tempfile
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "..", "n-hans_amd", "csrc")
+
+
+def vgprs(text):
+    """set of VGPR numbers an instruction line mentions"""
+    out = set()
+    for a, b in re.findall(r"\bv\[(\d+):(\d+)\]", text):
+        out.update(range(int(a), int(b) + 1))
+    for a in re.findall(r"\bv(\d+)\b", text):
+        out.add(int(a))
+    return out
+
+
+def check_kernel(name, lines):
+    errs = []
+    body = "\n".join(lines)
+    m = re.search(r"\.amdhsa_private_segment_fixed_size (\d+)", body)
+    # (the descriptor follows the code; scratch shows as scratch_ instructions as well)
+    if any("scratch_" in l for l in lines):
+        errs.append("scratch instructions (spills)")
+    # asm blocks
+    blocks, cur, inasm = [], None, False
+    for i, l in enumerate(lines):
+        if "#ASMSTART" in l:
+            inasm, cur = True, [i, i, []]
+        elif "#ASMEND" in l:
+            inasm = False
+            cur[1] = i
+            blocks.append(cur)
+        elif inasm:
+            cur[2].append(l)
+    loads = [b for b in blocks if sum("global_load_dwordx4" in l for l in b[2]) == 8]
+    mults = [b for b in blocks if any("v_mfma" in l for l in b[2])]
+    if len(loads) < 3 or len(mults) < 4:
+        return errs + ["expected >= 3 weight-request blocks and 4 multiply blocks, found %d / %d" % (len(loads), len(mults))]
+
+    def load_regs(b):
+        r = set()
+        for l in b[2]:
+            mm = re.search(r"global_load_dwordx4 v\[(\d+):(\d+)\]", l)
+            r.update(range(int(mm.group(1)), int(mm.group(2)) + 1))
+        return frozenset(r)
+
+    def mult_regs(b):
+        used, vops = set(), set()
+        for l in b[2]:
+            mm = re.search(r"v_mfma\S+ v\[\d+:\d+\], v\[(\d+):(\d+)\], v\[(\d+):(\d+)\]", l)
+            if mm:
+                used.update(range(int(mm.group(1)), int(mm.group(2)) + 1))
+                vops.update(range(int(mm.group(3)), int(mm.group(4)) + 1))
+        return frozenset(used), vops
+
+    for b in loads:
+        if len(load_regs(b)) != 32:
+            errs.append("a request block writes %d registers" % len(load_regs(b)))
+    for b in mults:
+        if "s_waitcnt vmcnt(4)" not in b[2][0]:
+            errs.append("a multiply block does not open with s_waitcnt vmcnt(4)")
+        w, v = mult_regs(b)
+        if w & v:
+            errs.append("an MFMA takes a weight register as its V operand")
+    # program order from the first request to the loop's backward branch, the loop body twice (wrap-around)
+    first, last = loads[0][0], mults[-1][1]
+    back = None
+    labels = {m.group(1): i for i, l in enumerate(lines) for m in [re.match(r"^(\.LBB\d+_\d+):", l)] if m}
+    for i in range(last, min(last + 200, len(lines))):
+        m = re.search(r"s_cbranch_\w+ (\.LBB\d+_\d+)", lines[i])
+        if m and labels.get(m.group(1), 1 << 30) < i:
+            back = (labels[m.group(1)], i)
+            break
+    if back is None:
+        for i in range(last, first, -1):
+            m = re.search(r"s_cbranch_\w+ (\.LBB\d+_\d+)", lines[i])
+            if m and labels.get(m.group(1), 1 << 30) < i:
+                back = (labels[m.group(1)], i)
+                break
+    if back is None:
+        return errs + ["no backward branch found behind the multiply blocks"]
+    order = list(range(first, back[1] + 1)) + list(range(back[0], back[1] + 1))
+    kind = {}
+    for b in loads:
+        kind[b[0]] = ("load", load_regs(b), b)
+    for b in mults:
+        kind[b[0]] = ("mult", mult_regs(b)[0], b)
+    skip = set()
+    for b in loads + mults:
+        skip.update(range(b[0], b[1] + 1))
+    # every request: its registers stay untouched until the multiply blocks that consume them (the next one or two in
+    # program order) have run
+    for pos, i in enumerate(order[:back[1] + 1 - first]):
+        if i not in kind or kind[i][0] != "load":
+            continue
+        R = kind[i][1]
+        nm, touched, lastgood = 0, [], None
+        for j in order[pos + 1:]:
+            if j in kind and kind[j][0] == "mult":
+                if kind[j][1] != R:
+                    break
+                nm += 1
+                lastgood = len(touched)
+                if nm == 2:
+                    break
+            elif j in kind and kind[j][0] == "load":
+                break
+            elif j not in skip:
+                code = lines[j].split(";")[0]
+                if vgprs(code) & R:
+                    touched.append((j, lines[j].strip()))
+        if nm == 0:
+            errs.append("request at line %d: the next multiply block reads other registers" % i)
+        for j, t in touched[:lastgood or 0]:
+            errs.append("line %d touches a weight register between request and use: %s" % (j, t))
+    inasm = False
+    for i in range(first, back[1] + 1):
+        l = lines[i]
+        if "#ASMSTART" in l:
+            inasm = True
+        elif "#ASMEND" in l:
+            inasm = False
+        code = l.split(";")[0]
+        if not inasm and re.search(r"s_waitcnt.*vmcnt", code) and "vmcnt(12)" not in code and "vmcnt(4)" not in code:
+            errs.append("line %d: a wait the source does not contain: %s" % (i, l.strip()))
+        if not inasm and re.match(r"\s*ds_", code):
+            errs.append("line %d: compiler-visible LDS access inside the K loop: %s" % (i, l.strip()))
+    return errs
+
+
+def main():
+    with tempfile.TemporaryDirectory() as tmp:
+        out = os.path.join(tmp, "w.s")
+        cmd = ["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "--cuda-device-only", "-S",
+               os.path.join(CSRC, "conv_wino128.hip"), "-o", out] + sys.argv[1:]
+        subprocess.run(cmd, check=True, cwd=CSRC)
+        text = open(out).read().split("\n")
+    # split into kernels
+    kernels, cur = {}, None
+    for l in text:
+        m = re.match(r"^(_ZN5nhans12conv_wino128\w+):", l)
+        if m:
+            cur = m.group(1)
+            kernels[cur] = []
+        elif cur is not None:
+            if l.startswith(".Lfunc_end"):
+                cur = None
+            else:
+                kernels[cur].append(l)
+    if not kernels:
+        print("no conv_wino128 kernel found")
+        return 1
+    rc = 0
+    for k, lines in kernels.items():
+        errs = check_kernel(k, lines)
+        print(k, "OK" if not errs else "FAILED")
+        for e in errs[:20]:
+            print("   ", e)
+        rc |= bool(errs)
+    return rc
+
+
+if __name__ == "__main__":
+    sys.exit(main())
