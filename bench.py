@@ -60,7 +60,7 @@ def parse(argv=None):
     p.add_argument("--frames-per-chunk", type=int, default=0)
     p.add_argument("--precision", default="f16x3", choices=["f32", "f16x3"])
     p.add_argument("--option", action="append", default=[], metavar="KEY=VALUE",
-                   help="nhans_set_option knob for an A/B run (e.g. quad_workgroups=1); recorded in config")
+                   help="nhans_set_option knob for an A/B run (e.g. winograd=0); recorded in config")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-kernel-pass", action="store_true", help="skip the extra profiled pass (rocprofv3 runs)")
     p.add_argument("--ceiling-seconds", type=float, default=2.0,

@@ -97,8 +97,8 @@ void nhans_destroy(nhans_ctx* ctx);
  *          "conv_variant" (-1: automatic, default; 0: register-staged 128-pixel kernel; 1: LDS-DMA
  *           256-pixel kernel; 2: halo-reuse kernel with producer/consumer waves where the conv
  *           allows it (512-pixel tiles for the 64-channel convs), the same pipeline with one staged image per tap
- *           for the strided / VALID convs with >= 128 output channels, else 1; 3: as 2 with the
- *           64-channel convs on 2-D 256-pixel tiles -- same results within rounding, different speed).
+ *           for the strided / VALID convs with >= 128 output channels, else 1 -- same results
+ *           within rounding, different speed).
  *          "epilogue_wide" (1, default: split-f16 epilogues move 8 channels = 16-byte pieces per thread;
  *           0: 4 channels -- identical bits, kept for A/B),
  *          "consumer_interleave" (1, default: the MFMA waves of the halo kernel issue their LDS operand
@@ -111,22 +111,16 @@ void nhans_destroy(nhans_ctx* ctx);
  *           |x| of every tensor in the calls that follow (any precision; precision 0 cannot saturate and is what a
  *           calibration on own data should use); 0: stop and set every e so that the recorded maximum is stored as
  *           at most 2^8; 2: stop and only RAISE exponents (what a caller does after a saturated batch: rerun it at
- *           precision 0 inside the bracket -- that is the correct result for it -- and go on at precision 1).
- *           Stopping synchronises the device.  A maximum that is not finite is refused with NHANS_EINVAL.),
+ *           precision 0 inside the bracket -- that is the correct result for it -- and go on at precision 1);
+ *           3: stop and discard (the recorded pass failed).  Stopping synchronises the device.  A tensor the pass never
+ *           wrote keeps its exponent.  A maximum that is not finite is refused with NHANS_EINVAL by 0 and ignored by 2
+ *           (a NaN / Inf INPUT raises the flag as well and says nothing about the range).  Exponents raised after a
+ *           saturated batch persist: the bits of later batches depend on that history -- set them explicitly
+ *           (nhans_set_activation_exponents) where ranks or runs must agree bit for bit.),
  *          "winograd" (1, default: in split-f16 mode the stride-1 4x4 convs of the residual stack run as 1-D
  *           Winograd convolutions F(5,4) along the image width, 2.5 x fewer matrix-core MACs -- conv_wino.hip;
  *           0: the direct kernels for every conv -- results agree to ~1e-5 on the logits),
- *          The next three select kernels that exist only in a `make AB=1` build (the default library refuses them
- *          with NHANS_EINVAL; option "ab_build" returns NHANS_OK in such a build):
- *          "persistent_tiles" (0, default; 1: launches with >= 2 tiles per CU run the halo kernels as persistent
- *           workgroups whose DMA pipeline runs on across tile boundaries -- identical bits, measured 2-3 %
- *           slower, kept so that the measurement can be repeated),
- *          "quad_workgroups" (0, default; 1: the stride-1 convs with N % 128 == 0 run on four-wave workgroups, two
- *           resident per CU, every wave multiplying and issuing DMA (conv_igemm_quad.hip) -- identical bits, 10 %
- *           fewer clock ticks per tile, and the same wall time because the chip then clocks lower at its socket
- *           power cap; kept as the measurement of that cap).
- * (A `make DEV=1` build adds "debug_cycles_ptr" and the NHANS_ABLATE / NHANS_HALO2D environment
- * switches used by tools/; the default build has no developer hooks and reads no environment.)
+ * (A `make DEV=1` build adds "debug_cycles_ptr" and the NHANS_ABLATE environment switch used by tools/; the default build has no developer hooks and reads no environment.)
  * Besides the workspace a context holds 64 MB of split-K scratch for the few launches that are
  * too small to fill the chip (the head's dense layer, the embedding tower at a few clips). */
 int nhans_set_option(nhans_ctx* ctx, const char* key, int64_t value);

@@ -344,30 +344,20 @@ double launch_conv_igemm(const ConvArgs& a0, hipStream_t s, const char** kernel,
         // (layers marked for grouped summation / split-K always take the LDS-DMA kernel, whatever the
         // launch size: the choice must not depend on the batch)
         const bool halo_ok = a.variant >= 2 && a.kgroup >= 0;
-        bool wino = false, wino128 = false;
-        if (halo_ok && conv_wino128_eligible(a)) {
-            // the same with 128 tile-pixels per transformed-weight fragment (conv_wino128.hip)
-            launch_conv_wino128(a, s);
-            name = "conv_wino<128>";
-            wino128 = true;
-        } else if (halo_ok && conv_wino_eligible(a)) {
-            // stride-1 k x k convs of the stack: 1-D Winograd along W, 2.5 x fewer MFMAs (conv_wino.hip)
+        bool wino = false;
+        if (halo_ok && conv_wino_eligible(a)) {
+            // stride-1 4 x 4 convs of the stack: 1-D Winograd along W, 2.5 x fewer MFMAs (conv_wino.hip)
             launch_conv_wino(a, s);
-            name = "conv_wino<64>";
+            name = "conv_wino<128>";
             wino = true;
-        } else if (halo_ok && !wide && a.variant == 2 && conv_igemm_halo_eligible(a)) {
+        } else if (halo_ok && !wide && conv_igemm_halo_eligible(a)) {
             // the 64-channel stride-1 convs: 512-pixel tiles
-            if (launch_conv_igemm_halo_persist(a, s)) name = "conv_igemm_halo_persist<64,512>";
-            else { launch_conv_igemm_halo(a, s); name = "conv_igemm_halo<64,512>"; }
-        } else if (halo_ok && wide && a.quad && conv_igemm_quad_eligible(a)) {
-            launch_conv_igemm_quad(a, s);
-            name = "conv_igemm_quad<128>";
-        } else if (halo_ok && launch_conv_igemm_halo2d(a, s)) {
-            name = "conv_igemm_halo2d<64>";          // (variant 3) 2-D 256-pixel tiles for the same layers
+            launch_conv_igemm_halo(a, s);
+            name = "conv_igemm_halo<64,512>";
         } else if (halo_ok && (a.halo64_tile512 = 0, conv_igemm_halo_eligible(a))) {
-            if (wide && launch_conv_igemm_halo_persist(a, s)) name = "conv_igemm_halo_persist<128>";
-            else { launch_conv_igemm_halo(a, s); name = wide ? "conv_igemm_halo<128>" : "conv_igemm_halo<64>"; }
-        } else if (halo_ok && wide && a.variant == 2 && conv_igemm_halo_pw_eligible(a)) {
+            launch_conv_igemm_halo(a, s);
+            name = wide ? "conv_igemm_halo<128>" : "conv_igemm_halo<64>";
+        } else if (halo_ok && wide && conv_igemm_halo_pw_eligible(a)) {
             // strided / VALID convs: the producer-consumer pipeline with one staged image per tap
             launch_conv_igemm_halo_pw(a, s);
             name = "conv_igemm_halo_pw<128>";
@@ -377,7 +367,7 @@ double launch_conv_igemm(const ConvArgs& a0, hipStream_t s, const char** kernel,
                                 : (wide ? "conv_igemm_dma<128>" : "conv_igemm_dma<64>");
         }
         if (kernel) *kernel = name;
-        if (mfma_flops) *mfma_flops = wino128 ? conv_wino128_mfma_flops(a) : wino ? conv_wino_mfma_flops(a) : (a.prec == 1 ? 3.0 : 1.0) * 2.0 * (double)a.M * k * (double)a.N;
+        if (mfma_flops) *mfma_flops = wino ? conv_wino_mfma_flops(a) : (a.prec == 1 ? 3.0 : 1.0) * 2.0 * (double)a.M * k * (double)a.N;
         return 2.0 * (double)a.M * k * (double)a.Nreal;
     }
     if (kernel) *kernel = wide ? "conv_igemm<128>" : "conv_igemm<64>";

@@ -1,6 +1,6 @@
-// Shared by the Winograd conv kernels (conv_wino.hip, conv_wino128.hip): the split / un-split helpers, the layout
-// constant of the exchanged accumulator tiles and the fused output-transform + block epilogue of a 512-thread
-// consumer group (one pass = 64 tile-pixels x 64 channels x 8 positions through LDS).
+// Part of conv_wino.hip: the split / un-split helpers, the layout of the exchanged accumulator tiles and the fused
+// output-transform + block epilogue of the workgroup's 512 threads (one pass = 64 tile-pixels x 64 channels x 8
+// positions through LDS; the kernel runs two).
 #pragma once
 #include "conv_epilogue.h"
 #include <cstddef>

@@ -21,7 +21,11 @@ void keep(hipError_t e, const char* where) {
 }
 }  // namespace
 
-void note_launch(const char* kernel) { keep(hipGetLastError(), kernel); }
+void note_launch(const char* kernel, hipError_t launch_rc) {
+    if (launch_rc == hipSuccess) return;
+    (void)hipGetLastError();        // (a failed launch of OURS also sets the sticky error: take it back out, it is reported by return code)
+    keep(launch_rc, kernel);
+}
 
 void set_max_dynamic_lds(const void* fn, size_t bytes, unsigned long long* done_mask, const char* kernel) {
     int dev = 0;
@@ -46,10 +50,6 @@ hipError_t take_launch_error(const char** kernel) {
 #ifdef NHANS_DEV
 int dev_ablate() {
     static const int v = [] { const char* e = getenv("NHANS_ABLATE"); return e ? atoi(e) : 0; }();
-    return v;
-}
-bool dev_halo2d_enabled() {
-    static const bool v = [] { const char* e = getenv("NHANS_HALO2D"); return !(e && atoi(e) == 0); }();
     return v;
 }
 #endif

@@ -3,6 +3,9 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <tuple>
+#include <utility>
+
 namespace nhans {
 
 constexpr int kWin = 400, kHop = 160, kBins = 201, kMixWin = 35, kCtxFrames = 200, kEmb = 512;
@@ -16,39 +19,37 @@ constexpr int64_t kMaxFramesPerChunk = ((int64_t)1 << 31) / ((int64_t)kMixWin * 
 #ifdef NHANS_DEV
 constexpr bool kDev = true;
 int dev_ablate();          // getenv("NHANS_ABLATE"), read once
-bool dev_halo2d_enabled(); // getenv("NHANS_HALO2D") != "0"
 #else
 constexpr bool kDev = false;
 constexpr int dev_ablate() { return 0; }
-constexpr bool dev_halo2d_enabled() { return true; }
-#endif
-
-// The A/B conv kernels that every measurement of rounds 1-2 found no faster than the default ones
-// (persistent workgroups: conv_igemm_halop.hip; four-wave workgroups, two per CU: conv_igemm_quad.hip;
-// 2-D 256-pixel tiles for the 64-channel convs: conv_igemm_halo2d.hip) are compiled only into a
-// `make AB=1` build (-DNHANS_AB), where the options persistent_tiles / quad_workgroups /
-// conv_variant 3 select them; the default library is built without them and refuses those options.
-#ifdef NHANS_AB
-constexpr bool kAB = true;
-#else
-constexpr bool kAB = false;
 #endif
 
 // ---------------------------------------------------------------------------------------------
-// Launch-error channel (launch_status.hip).  Every launcher calls note_launch() right after its
-// hipLaunchKernelGGL and set_max_dynamic_lds() before a launch that needs more than 64 KB of LDS;
-// the first failure of the calling thread is kept until the C-ABI entry point collects it with
-// take_launch_error() and returns NHANS_EHIP.  Nothing is launched silently wrong.
-void note_launch(const char* kernel);
+// Launch-error channel (launch_status.hip).  Every kernel of the library is launched through NHANS_LAUNCH, which takes
+// the launch's OWN return code (hipLaunchKernel) -- not the runtime's sticky per-thread "last error", which an earlier
+// HIP call of the application may have left set and which is neither blamed on this library nor consumed on the
+// application's behalf --, and set_max_dynamic_lds() runs before a launch that needs more than 64 KB of LDS; the first
+// failure of the calling thread is kept until the C-ABI entry point collects it with take_launch_error() and returns
+// NHANS_EHIP.  Nothing is launched silently wrong.
+void note_launch(const char* kernel, hipError_t launch_rc);
 // hipFuncAttributeMaxDynamicSharedMemorySize is a per-DEVICE attribute: `done_mask` (one static per
 // kernel instantiation) has one bit per device id.
 void set_max_dynamic_lds(const void* fn, size_t bytes, unsigned long long* done_mask, const char* kernel);
 hipError_t take_launch_error(const char** kernel);
+template <typename... P, size_t... I>
+inline hipError_t launch_packed(void (*kernel)(P...), dim3 grid, dim3 block, size_t lds, hipStream_t s, std::tuple<std::decay_t<P>...>& params,
+                                std::index_sequence<I...>) {
+    void* ptrs[] = {static_cast<void*>(&std::get<I>(params))...};
+    return hipLaunchKernel(reinterpret_cast<const void*>(kernel), grid, block, ptrs, lds, s);
+}
+template <typename... P, typename... A>
+inline void launch_checked(const char* name, void (*kernel)(P...), dim3 grid, dim3 block, size_t lds, hipStream_t s, A&&... args) {
+    static_assert(sizeof...(P) == sizeof...(A), "kernel argument count");
+    std::tuple<std::decay_t<P>...> params(std::forward<A>(args)...);        // converted to the kernel's parameter types
+    note_launch(name, launch_packed<P...>(kernel, grid, block, lds, s, params, std::index_sequence_for<P...>{}));
+}
 #define NHANS_LAUNCH(NAME, KERNEL, GRID, BLOCK, LDS, STREAM, ...)                                  \
-    do {                                                                                           \
-        hipLaunchKernelGGL(KERNEL, GRID, BLOCK, LDS, STREAM, __VA_ARGS__);                         \
-        ::nhans::note_launch(NAME);                                                                \
-    } while (0)
+    ::nhans::launch_checked(NAME, KERNEL, GRID, BLOCK, LDS, STREAM, __VA_ARGS__)
 
 // bit set in *sat by the split-f16 writers when an activation does not fit f16 (|v| >= 65504 or NaN)
 constexpr int kSatActivation = 1;
@@ -130,17 +131,12 @@ struct ConvArgs {
     float sat_limit;
     int* sat;              // prec 1: device flag word, kSatActivation is OR-ed in when a stored activation saturates
     int variant;           // 0: 128-pixel / 4-wave register-staged kernel, 1: 256-pixel / 8-wave LDS-DMA kernel,
-                           // 2, 3: LDS-DMA kernel with halo reuse across the KW taps where the conv allows it
+                           // 2: LDS-DMA kernels with producer / consumer waves and halo reuse across the KW taps
     int epi8;              // split-NHWC outputs: 8 channels per thread in the epilogue sweep (16-byte pieces), default;
                            // 0 = the 4-channel sweep (A/B and parity cross-check; same bits)
     int ilv;               // halo kernel: operand reads between the MFMAs, front-loaded in each half (default 1); 2 = spread
                            // evenly over the half; 0 = read block then MFMA block (the round-1 order) -- A/B knob, same bits
-    int persist;           // halo kernels: persistent workgroups walking several tiles with the DMA pipeline kept
-                           // running across tile boundaries (conv_igemm_halop.hip) when the launch has >= 2 tiles
-                           // per CU (default 0: measured 2-3 % slower than one tile per workgroup; same bits)
-    int quad;              // N % 128 == 0, f16x3, stride-1 convs: four-wave workgroups, two per CU (conv_igemm_quad.hip)
-    int halo64_tile512;    // halo kernel, 64-channel convs: 512-pixel tiles (variant 2) instead of the 2-D
-                           // 256-pixel tiles of conv_igemm_halo2d.hip / 256-pixel runs (variant 3)
+    int halo64_tile512;    // halo kernel, 64-channel convs: 512-pixel tiles (set by the launcher)
     long long* dbg;        // NHANS_DEV builds only: 4 s_memtime stamps per workgroup [start, loop, epilogue, end]
     FastDiv fdHoWo, fdWo;
     FastDiv fdWP;          // Wo + KW - 1 (filled in by launch_conv_igemm_halo)
@@ -155,15 +151,11 @@ struct ConvArgs {
     // 1-D Winograd along W (conv_wino.hip).  Caller: wino_u / wino_ws (null = this conv has no Winograd form) and
     // wino on/off; the launcher fills in the rest: outputs per tile, tile-pixel block (rows x tiles, <= 64), blocks
     // per frame, tiles per image row
-    const float* wino_u;   // conv_wino.hip's pack (16-channel chunks)
-    const float* wino_u8;  // conv_wino128.hip's pack (8-channel chunks, two filter rows per k-step)
+    const float* wino_u;
     const float* wino_ws;
-    int wino;              // 0 off, 1 conv_wino.hip (M = 64 tile-pixels per weight fragment), 2 conv_wino128.hip where its pack exists
+    int wino;
     int wino_m, wino_tr, wino_tj, wino_nrb, wino_ncb, wino_ntile;
     FastDiv wino_fd_bpf, wino_fd_nnb, wino_fd_ncb;   // blocks per frame, channel blocks, column blocks (block decode)
-    // 2-D pixel tiles (conv_igemm_halo2d.hip; filled in by its launcher): th x tw output pixels of one
-    // image per workgroup, ntr x ntc tiles per image
-    int t2_th, t2_tw, t2_ntr, t2_ntc;
 };
 
 // returns algorithmic FLOPs of the launch (2*M*K*Nreal); *kernel (optional) names the variant that ran
@@ -173,26 +165,11 @@ double launch_conv_igemm(const ConvArgs& a, hipStream_t s, const char** kernel =
 double conv_wino_mfma_flops(const ConvArgs& a);                 // conv_wino.hip
 void launch_conv_igemm_dma(const ConvArgs& a, hipStream_t s);   // conv_igemm_dma.hip
 bool conv_wino_eligible(const ConvArgs& a);                     // conv_wino.hip
-bool conv_wino_shape_ok(const ConvArgs& a);
 void launch_conv_wino(const ConvArgs& a, hipStream_t s);
-bool conv_wino128_eligible(const ConvArgs& a);                  // conv_wino128.hip
-void launch_conv_wino128(const ConvArgs& a, hipStream_t s);
-double conv_wino128_mfma_flops(const ConvArgs& a);
 bool conv_igemm_halo_eligible(const ConvArgs& a);               // conv_igemm_halo.hip
 void launch_conv_igemm_halo(const ConvArgs& a, hipStream_t s);
 bool conv_igemm_halo_pw_eligible(const ConvArgs& a);            // the same pipeline without halo reuse (strided / VALID convs)
 void launch_conv_igemm_halo_pw(const ConvArgs& a, hipStream_t s);
-#ifdef NHANS_AB
-bool conv_igemm_quad_eligible(const ConvArgs& a);                         // conv_igemm_quad.hip
-void launch_conv_igemm_quad(const ConvArgs& a, hipStream_t s);
-bool launch_conv_igemm_halo_persist(const ConvArgs& a, hipStream_t s);   // conv_igemm_halop.hip; false = not applicable, nothing launched
-bool launch_conv_igemm_halo2d(const ConvArgs& a, hipStream_t s);  // conv_igemm_halo2d.hip; false = not eligible, nothing launched
-#else
-inline bool conv_igemm_quad_eligible(const ConvArgs&) { return false; }
-inline void launch_conv_igemm_quad(const ConvArgs&, hipStream_t) {}
-inline bool launch_conv_igemm_halo_persist(const ConvArgs&, hipStream_t) { return false; }
-inline bool launch_conv_igemm_halo2d(const ConvArgs&, hipStream_t) { return false; }
-#endif
 
 // ---------------------------------------------------------------------------------------------
 // Small kernels (aux_kernels.hip)

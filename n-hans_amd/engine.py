@@ -93,9 +93,12 @@ class Engine:
             ca_t, ca_off = self._dev(ctx_a)
             cb_t, cb_off = self._dev(ctx_b)
             self.enhance_device(mix_t, mix_off, ca_t, ca_off, cb_t, cb_off)
-        finally:
+        except BaseException:
             self.set_precision(before)
-            self.set_option("calibrate", 2 if raise_only else 0)
+            self.set_option("calibrate", 3)          # the pass failed: close the bracket, keep the exponents
+            raise
+        self.set_precision(before)
+        self.set_option("calibrate", 2 if raise_only else 0)
         return self.activation_exponents()
 
     def take_status(self):
@@ -197,9 +200,16 @@ class Engine:
             try:
                 res = self.enhance_device(mix_t, mix_off, ca_t, ca_off, cb_t, cb_off, want_mixed, taps)
                 self.take_status()
-            finally:
+            except BaseException:
                 self.set_precision("f16x3")
+                self.set_option("calibrate", 3)
+                raise
+            self.set_precision("f16x3")
+            try:
+                # (raise-only; maxima that are not finite -- the flag is also raised by a NaN / Inf INPUT -- are skipped)
                 self.set_option("calibrate", 2)
+            except hip.NhansError as err:          # the f32 result stands whatever the exponent update says
+                warnings.warn("N-HANS: activation exponents not updated after the f32 rerun: %s" % err)
         torch.cuda.synchronize(self.device)
         out = {"denoised_wav": [], "mixed_wav": []}
         den = res["denoised_wav"].cpu().numpy()

@@ -9,7 +9,7 @@ float32 at the end:
   * the 16 conditioning projections (SN/main.py:139-148) -> one [1024, 3840] matrix;
   * HWIO kernels -> the MFMA fragment order of conv_igemm.hip (`pack_igemm`).
 
-Blob layout (little endian): header {char magic[8]="NHANSFW1"; u32 version=1; u32 n_entries;
+Blob layout (little endian): header {char magic[8]="NHANSFW1"; u32 version=BLOB_VERSION; u32 n_entries;
 u64 total_bytes}, then n_entries x {char name[48]; u64 offset; u64 nfloats}, then float32 arrays
 at 256-byte-aligned offsets.
 """
@@ -21,6 +21,10 @@ import numpy as np
 from . import spec
 
 F64 = np.float64
+# Version of the packing conventions below; nhans_create refuses any other (a blob folded by an older tree would load
+# and compute wrong results: version 1 walked K as (filter row, chunk, column) and, later, (chunk, row, column) under
+# the same number; 2 = (chunk, row, column) for the direct kernels and the 8-channel / two-row k-steps of pack_wino).
+BLOB_VERSION = 2
 
 
 def _bn(W, scope):
@@ -99,7 +103,7 @@ def pack_igemm_h3(wkn, scale, npad=None):
 
 
 # ------------------------------------------------------------------------------ 1-D Winograd along W
-# conv_wino.hip runs the stride-1 k x k convs of the stack as F(m, k) along the image width, plain
+# conv_wino.hip runs the stride-1 4 x 4 convs of the stack as F(m, k) along the image width, plain
 # accumulation over the filter rows and the channels: per tile of m output columns the 8 transformed
 # positions V_p = sum_x BT[p][x] d[x] of its 8 input columns are multiplied with the transformed
 # filter U_p[kh] = sum_kw G[p][kw] w[kh][kw] -- 8*kh instead of m*k*kh products per channel pair
@@ -182,39 +186,16 @@ def wino_eligible(kh, kw, sh, sw, cin, cout):
 
 
 def pack_wino(w4):
-    """HWIO weights [KH, KW, C, N] (BatchNorm scale folded in) -> (packed U as a float32 view of
-    f16 bits, per-channel unscale vector).  U_p[kh][c][n] = sum_kw G[p][kw] w[kh][kw][c][n], scaled
-    per output channel by a power of two into [32, 64), split hi/lo; laid out
-    [N/64][p 8][C/16][KH][nt 2][h 2][lane 64][e 8]: lane l, element e of the fragment of
-    (64-channel block nb, position p, 16-channel chunk cc, filter row kh, 32-channel tile nt) holds
-    k = 16 cc + 8 (l >> 5) + e, column 64 nb + 32 nt + (l & 31) -- the wave that owns position p streams its
-    fragments strictly sequentially (conv_wino.hip)."""
-    kh, kw, c, n = w4.shape
-    assert c % 16 == 0 and n % 64 == 0
-    _, G, BT = wino_matrices(wino_outputs(kw), kw)
-    assert np.array_equal(BT, WINO_BT)
-    U = np.einsum("pk,hkcn->phcn", G, w4.astype(F64))              # [8, KH, C, N]
-    sc = col_scale(np.abs(U).reshape(-1, n))
-    Us = U * sc
-    hi = Us.astype(np.float16)
-    lo = (Us - hi.astype(F64)).astype(np.float16)
-    assert np.isfinite(hi).all()
-    parts = []
-    for a in (hi, lo):
-        a = a.reshape(WINO_N, kh, c // 16, 2, 8, n // 64, 2, 32)     # p, kh, cc, g8, e, nb, nt, col
-        parts.append(a.transpose(5, 0, 2, 1, 6, 3, 7, 4))            # nb, p, cc, kh, nt, g8, col, e
-    pk = np.stack(parts, axis=5)                                     # nb, p, cc, kh, nt, h, g8, col, e
-    return np.ascontiguousarray(pk).reshape(-1).view(np.float32), 1.0 / sc
-
-
-def pack_wino8(w4):
-    """The same transformed filter for conv_wino128.hip, whose MFMA k-step is 8 channels x TWO filter rows:
-    [N/64][p 8][C/8][s KH/2][nt 2][h 2][lane 64][e 8] -- lane l, element e of k-step s of 8-channel chunk c8 holds
-    filter row 2 s + (l >> 5), channel 8 c8 + e, column 64 nb + 32 nt + (l & 31).  Same values, scale and split as
-    pack_wino (the per-channel unscale vector is shared)."""
+    """HWIO weights [KH, KW, C, N] (BatchNorm scale folded in) -> (packed U as a float32 view of f16 bits,
+    per-channel unscale vector).  U_p[kh][c][n] = sum_kw G[p][kw] w[kh][kw][c][n], scaled per output channel by a
+    power of two into [32, 64), split hi/lo.  conv_wino.hip's MFMA k-step is 8 channels x TWO filter rows:
+    [N/64][p 8][C/8][s KH/2][nt 2][h 2][lane 64][e 8] -- lane l, element e of k-step s of 8-channel chunk c8 of
+    (64-channel block nb, position p) holds filter row 2 s + (l >> 5), channel 8 c8 + e, column 64 nb + 32 nt +
+    (l & 31); the wave that owns position p streams its fragments strictly sequentially."""
     kh, kw, c, n = w4.shape
     assert c % 16 == 0 and n % 64 == 0 and kh % 2 == 0
-    _, G, _ = wino_matrices(wino_outputs(kw), kw)
+    _, G, BT = wino_matrices(wino_outputs(kw), kw)
+    assert np.array_equal(BT, WINO_BT)
     U = np.einsum("pk,hkcn->phcn", G, w4.astype(F64))              # [8, KH, C, N]
     sc = col_scale(np.abs(U).reshape(-1, n))
     Us = U * sc
@@ -225,7 +206,8 @@ def pack_wino8(w4):
         a = a.reshape(WINO_N, kh // 2, 2, c // 8, 8, n // 64, 2, 32)  # p, s, g8, c8, e, nb, nt, col
         parts.append(a.transpose(5, 0, 3, 1, 6, 2, 7, 4))            # nb, p, c8, s, nt, g8, col, e
     pk = np.stack(parts, axis=5)                                     # nb, p, c8, s, nt, h, g8, col, e
-    return np.ascontiguousarray(pk).reshape(-1).view(np.float32)
+    assert np.isfinite(hi).all()
+    return np.ascontiguousarray(pk).reshape(-1).view(np.float32), 1.0 / sc
 
 
 def _pad(v, npad):
@@ -316,7 +298,6 @@ def fold_arrays(W, kind, split_f16=True):
                 w4 = w64("%s_conv%d/w" % (s, cv)) * scl
                 if cin_ == c and wino_eligible(g["kh"], g["kw"], st[0], st[1], cin_, c):
                     out["%s.c%d.wino" % (p, cv)], out["%s.c%d.wino.ws" % (p, cv)] = pack_wino(w4)
-                    out["%s.c%d.wino8" % (p, cv)] = pack_wino8(w4)
         for cv, sc, sh, bias in ((1, s1, h1, 0.0), (2, sa, ha, extra_bias)):
             q = "%s_conv%d" % (s, cv)
             # time + frequency position terms in one [Ho*Wo, C] table (one coalesced read per output)
@@ -358,7 +339,7 @@ def write_blob(arrays):
         chunks.append((off, a))
         off = (off + a.nbytes + 255) & ~255
     blob = bytearray(off)
-    blob[0:24] = struct.pack("<8sIIQ", b"NHANSFW1", 1, len(names), off)
+    blob[0:24] = struct.pack("<8sIIQ", b"NHANSFW1", BLOB_VERSION, len(names), off)
     for i, e in enumerate(entries):
         blob[24 + 64 * i:24 + 64 * (i + 1)] = e
     for o, a in chunks:

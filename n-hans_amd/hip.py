@@ -111,11 +111,6 @@ def mfma_ceiling(seconds, stream=None):
     return {"sustained_tflops": sus.value, "first_launch_tflops": first.value, "launches": n.value}
 
 
-def ab_build(handle):
-    """True when the library was built with `make AB=1` (the A/B conv kernels are present)."""
-    return load().nhans_set_option(handle, b"ab_build", 0) == 0
-
-
 def profile_dict(handle):
     lib = load()
     n = lib.nhans_profile_json(handle, None, 0)

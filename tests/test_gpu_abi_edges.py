@@ -181,3 +181,122 @@ def test_blob_without_the_tables_two_terms_still_runs(lib_built, weights_denoise
     e.close()
     assert np.abs(got - ref).max() <= 2e-5
     assert not any(n.startswith("conv_wino") for n in names)
+
+
+def test_blob_of_an_older_packing_version_is_refused(lib_built, weights_denoiser):
+    """Advisor finding (round 3): the K order of the packed weights changed while the blob said version 1, so a blob
+    folded by an older tree loaded and computed wrong results.  The version now follows the packing conventions
+    (fold.BLOB_VERSION); nhans_create refuses any other and says what to do."""
+    import struct
+    from nhans_amd import fold
+    blob = bytearray(fold.fold_weights(weights_denoiser, "denoiser"))
+    assert struct.unpack_from("<I", blob, 8)[0] == fold.BLOB_VERSION
+    struct.pack_into("<I", blob, 8, 1)
+    lib = hip.load()
+    buf = (ctypes.c_char * len(blob)).from_buffer(blob)
+    handle = ctypes.c_void_p(None)
+    rc = lib.nhans_create(hip.KIND_CODE["denoiser"], buf, len(blob), 0, ctypes.byref(handle))
+    assert rc == -1 and not handle.value
+    msg = lib.nhans_last_error()
+    assert b"packing version 1" in msg and b"re-fold" in msg
+
+
+def _hip_runtime():
+    for name in ("libamdhip64.so.7", "libamdhip64.so"):
+        try:
+            return ctypes.CDLL(name)
+        except OSError:
+            continue
+    pytest.skip("HIP runtime not loadable by soname")
+
+
+def test_an_error_the_application_left_pending_neither_blocks_nor_is_blamed(eng):
+    """Advisor finding (round 3): the entry points refused to run while the runtime's sticky per-thread error held
+    something the APPLICATION had left there.  Launches are now checked by their own return code: with an
+    out-of-memory error of the caller's pending, a C-ABI call runs, gives the same bits and reports no failure.
+    (Everything is allocated beforehand and no torch call sits between: torch itself raises on a pending error.)"""
+    rt = _hip_runtime()
+    lib = eng.lib
+    mix = apply.trim_to_frames(apply.normalise(synth.mixture(3, 0.2)))
+    wav = torch.from_numpy(mix).cuda()
+    off = hip.i64_array([0, len(mix)])
+    n = int(lib.nhans_num_frames(len(mix)))
+    lm = [torch.empty((n, spec.BINS), device="cuda") for _ in range(2)]
+    ph = [torch.empty((n, spec.BINS), device="cuda") for _ in range(2)]
+    stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert lib.nhans_stft_features(eng.handle, hip.ptr(wav), off, 1, 0, hip.ptr(lm[0]), hip.ptr(ph[0]), stream) == 0
+    p = ctypes.c_void_p(None)
+    rc = rt.hipMalloc(ctypes.byref(p), ctypes.c_size_t(1 << 60))
+    assert rc != 0                                                    # the application's own failure ...
+    pending = rt.hipPeekAtLastError()                                 # ... is now the thread's sticky error (or not, by runtime version)
+    rc2 = lib.nhans_stft_features(eng.handle, hip.ptr(wav), off, 1, 0, hip.ptr(lm[1]), hip.ptr(ph[1]), stream)
+    rc3 = lib.nhans_debug_launch_probe(1024, None)
+    after = rt.hipPeekAtLastError()
+    rt.hipGetLastError()                                              # (the application clears its own error)
+    assert rc2 == 0 and rc3 == 0, lib.nhans_last_error()
+    assert after in (pending, 0)                                      # not turned into something else by the library
+    torch.cuda.synchronize()
+    assert torch.equal(lm[0], lm[1]) and torch.equal(ph[0], ph[1])
+    assert eng.take_status() == 0
+
+
+def test_a_nan_clip_inside_a_batch_costs_only_itself(eng):
+    """Advisor finding (round 3): a batch that raises the saturation flag is rerun in f32 inside a raise-only
+    calibration bracket; non-finite maxima used to make the closing call fail and the whole batch was lost.  Two
+    things are pinned here: (i) a NaN sample in one clip poisons that clip only -- its neighbours equal the same clips
+    run alone, bit for bit, no exception (the ReLUs' v_max drops NaN, so this input does not even raise the flag);
+    (ii) a raise-only bracket closed over non-finite maxima keeps the exponents and reports success."""
+    mixes = [apply.trim_to_frames(apply.normalise(synth.mixture(20 + i, 0.2))) for i in range(3)]
+    ca = [apply.normalise(synth.silent()) for _ in range(3)]
+    cb = [apply.normalise(synth.noise_context(20 + i)) for i in range(3)]
+    alone = [eng.enhance([mixes[i]], [ca[i]], [cb[i]], want_mixed=False)["denoised_wav"][0] for i in (0, 2)]
+    exps = eng.activation_exponents()
+    bad = mixes[1].copy()
+    bad[700] = np.nan
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        out = eng.enhance([mixes[0], bad, mixes[2]], ca, cb, want_mixed=False)["denoised_wav"]
+    assert np.isnan(out[1]).any()
+    assert np.array_equal(out[0], alone[0]) and np.array_equal(out[2], alone[1])
+    assert eng.activation_exponents() == exps                                          # NaN says nothing about the range
+    eng.take_status()
+    # (ii) the f32 rerun's bracket with a non-finite maximum recorded: a NaN conditioning recording reaches every tensor
+    eng.set_option("calibrate", 1)
+    eng.set_precision("f32")
+    nanctx = cb[0].copy()
+    nanctx[1000] = np.nan
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        eng.enhance([mixes[0]], [ca[0]], [nanctx], want_mixed=False)
+    eng.set_precision("f16x3")
+    eng.set_option("calibrate", 2)                                                     # raise-only: skipped, not refused
+    assert eng.activation_exponents() == exps
+    eng.set_option("calibrate", 1)
+    eng.set_precision("f32")
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        eng.enhance([mixes[0]], [ca[0]], [nanctx], want_mixed=False)
+    eng.set_precision("f16x3")
+    with pytest.raises(hip.NhansError, match="non-finite"):
+        eng.set_option("calibrate", 0)                                                 # a calibration proper refuses ...
+    assert eng.activation_exponents() == exps                                          # ... and changes nothing
+    eng.take_status()
+    again = eng.enhance([mixes[0]], [ca[0]], [cb[0]], want_mixed=False)["denoised_wav"][0]   # and f16x3 goes on
+    assert np.array_equal(again, alone[0])
+
+
+def test_a_calibration_bracket_that_recorded_nothing_keeps_the_exponents(eng):
+    """Advisor finding (round 3): closing a bracket whose pass had failed before its first launch reset all 25
+    exponents to 0.  A tensor the pass never wrote keeps its exponent; "calibrate" 3 discards a bracket."""
+    exps = eng.activation_exponents()
+    assert any(e != 0 for e in exps)                                  # (the built-in calibration of nhans_create)
+    eng.set_option("calibrate", 1)
+    eng.set_option("calibrate", 0)
+    assert eng.activation_exponents() == exps
+    eng.set_option("calibrate", 1)
+    eng.set_option("calibrate", 3)
+    assert eng.activation_exponents() == exps
+    with pytest.raises(hip.NhansError):
+        eng.set_option("calibrate", 3)                                # no bracket is open

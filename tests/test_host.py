@@ -131,7 +131,7 @@ def test_fold_blob_structure(weights_denoiser):
     np.testing.assert_array_equal(arrs["m1.c1.wpk"], fold.pack_igemm(w))
     blob = fold.write_blob({"b": np.arange(5, dtype=np.float32), "a": np.ones(3, dtype=np.float32)})
     magic, ver, n, total = struct.unpack_from("<8sIIQ", blob, 0)
-    assert (magic, ver, n, total) == (b"NHANSFW1", 1, 2, len(blob))
+    assert (magic, ver, n, total) == (b"NHANSFW1", fold.BLOB_VERSION, 2, len(blob)) and fold.BLOB_VERSION == 2
     name, off, cnt = struct.unpack_from("<48sQQ", blob, 24)
     assert name.rstrip(b"\0") == b"a" and off % 256 == 0 and cnt == 3
     assert np.frombuffer(blob, np.float32, 3, off).tolist() == [1, 1, 1]
@@ -460,8 +460,8 @@ def test_winograd_matrices_are_exact_and_match_the_kernel_constants():
 
 
 def test_winograd_weight_pack_reproduces_the_direct_convolution():
-    """fold.pack_wino -> the fragment order conv_wino.hip streams ([N/64][p][C/16][KH][nt][hi|lo][lane][8]): unpack it
-    with the kernel's own index arithmetic, run the 1-D Winograd algorithm in float64 (V = BT d along W, M_p = sum over
+    """fold.pack_wino -> the fragment order conv_wino.hip streams ([N/64][p][C/8][KH/2][nt][hi|lo][lane][8]: a k-step
+    of the MFMA is 8 channels x two filter rows): unpack it with the kernel's own index arithmetic, run the 1-D Winograd algorithm in float64 (V = BT d along W, M_p = sum over
     filter rows and channels, Y = AT M) and compare with the direct SAME convolution."""
     from nhans_amd import fold
     rng = np.random.default_rng(1)
@@ -469,13 +469,14 @@ def test_winograd_weight_pack_reproduces_the_direct_convolution():
     w4 = rng.standard_normal((KH, KH, C, N)) / np.sqrt(KH * KH * C)
     x = rng.standard_normal((H, W, C))
     pk, ws = fold.pack_wino(w4)
-    halfs = pk.view(np.float16).astype(np.float64).reshape(N // 64, 8, C // 16, KH, 2, 2, 64, 8)   # nb p cc kh nt h lane e
+    halfs = pk.view(np.float16).astype(np.float64).reshape(N // 64, 8, C // 8, KH // 2, 2, 2, 64, 8)   # nb p c8 s nt h lane e
     U = np.zeros((8, KH, C, N))
     for lane in range(64):
         for e in range(8):
-            # lane l, element e of fragment (nb, p, cc, kh, nt): k = 16 cc + 8 (l >> 5) + e, column 64 nb + 32 nt + (l & 31)
-            U[:, :, 8 * (lane >> 5) + e::16, (lane & 31)::32] = (halfs[:, :, :, :, :, 0, lane, e] + halfs[:, :, :, :, :, 1, lane, e]) \
-                .transpose(1, 3, 2, 0, 4).reshape(8, KH, C // 16, (N // 64) * 2)
+            # lane l, element e of fragment (nb, p, c8, s, nt): filter row 2 s + (l >> 5), channel 8 c8 + e,
+            # column 64 nb + 32 nt + (l & 31)
+            U[:, (lane >> 5)::2, e::8, (lane & 31)::32] = (halfs[:, :, :, :, :, 0, lane, e] + halfs[:, :, :, :, :, 1, lane, e]) \
+                .transpose(1, 3, 2, 0, 4).reshape(8, KH // 2, C // 8, (N // 64) * 2)
     U *= ws[None, None, None, :]                                   # undo the per-channel power-of-two scale
     m = fold.wino_outputs(KH)
     AT, G, BT = fold.wino_matrices(m, KH)
@@ -494,3 +495,15 @@ def test_winograd_weight_pack_reproduces_the_direct_convolution():
         for kw in range(KH):
             ref += np.einsum("hwc,cn->hwn", xp[kh:kh + H, kw:kw + W], w4[kh, kw])
     assert np.abs(out[:, :W] - ref).max() < 2e-6 * np.abs(ref).max() + 1e-6
+
+
+def test_winograd_kernel_isa_keeps_its_hand_counted_waits():
+    """conv_wino.hip requests its weights inside inline asm and waits for them with its own s_waitcnt; the compiler
+    believes such a register is valid when the asm statement ends.  tools/check_wino_isa.py compiles the kernel and
+    verifies that nothing touches a requested register before the wait, that no spill and no compiler-generated
+    vector-memory wait or LDS access sits in the K loop (needs hipcc only)."""
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_wino_isa.py")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "OK" in r.stdout

@@ -16,11 +16,8 @@ from nhans_amd.apply import normalise, trim_to_frames  # noqa: E402
 def main():
     runs = int(sys.argv[1]) if len(sys.argv) > 1 else 100
     clips = int(sys.argv[2]) if len(sys.argv) > 2 else 2
-    for prec, opts in (("f16x3", {}), ("f16x3", {"winograd": 0}), ("f16x3", {"quad_workgroups": 1}), ("f32", {})):
+    for prec, opts in (("f16x3", {}), ("f16x3", {"winograd": 0}), ("f32", {})):
         eng = engine.Engine("denoiser", precision=prec)
-        if "quad_workgroups" in opts and not hip.ab_build(eng.handle):   # needs a `make AB=1` library
-            eng.close()
-            continue
         for k, v in opts.items():
             eng.set_option(k, v)
         mixes = [trim_to_frames(normalise(synth.mixture(i, 10.0 if i % 2 == 0 else 3.7))) for i in range(clips)]
