@@ -74,6 +74,12 @@ def parse(argv=None):
     p.add_argument("--share-device0", action="store_true",
                    help="functional check of the N > 1 code path on a one-GPU box: every rank uses device 0 and the "
                         "all-gather runs over gloo (RCCL refuses two ranks on one device); not a measurement")
+    p.add_argument("--rank-timeout", type=float, default=1800.0,
+                   help="self-launched ranks (--gpus N without a launcher): give up after this many seconds (0 = never)")
+    p.add_argument("--debug-fail-rank", type=int, default=-1,
+                   help="test hook: this rank exits with code 3 before it joins the process group")
+    p.add_argument("--debug-hang-rank", type=int, default=-1,
+                   help="test hook: this rank sleeps instead of starting (a rank stuck at communicator initialisation)")
     return p.parse_args(argv)
 
 
@@ -201,27 +207,56 @@ def rms_check(W, kind, eng, threads):
 
 
 def launch_ranks(a, argv):
-    """`python bench.py --gpus N` without a launcher: start the N ranks as child processes of this one
-    (which has not touched the GPU), one per GPU, rendezvous on 127.0.0.1, relay rank 0's JSON line,
-    and fail if any rank fails.  Under torch.distributed.run (WORLD_SIZE set) this is never reached."""
+    """`python bench.py --gpus N` without a launcher: start the N ranks as fresh child processes of this one (which has
+    not touched the GPU), one per GPU, rendezvous on 127.0.0.1, relay rank 0's JSON line.  All children are polled: the
+    first one that exits non-zero (a rank that dies at communicator initialisation would otherwise leave its siblings
+    in init_process_group until RCCL's own timeout) or --rank-timeout seconds without everybody finished end the
+    rest within seconds, and the launcher returns 1.  Under torch.distributed.run (WORLD_SIZE set) this is never reached."""
     import socket
+    import tempfile
+    import time
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
     procs = []
+    out0 = tempfile.TemporaryFile()                       # (a file, not a pipe: nobody has to drain it while we poll)
     for r in range(a.gpus):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(a.gpus), LOCAL_WORLD_SIZE=str(a.gpus),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out0 = procs[0].communicate()[0].decode()
-    codes = [p.wait() for p in procs]
-    sys.stdout.write(out0)
+                                      stdout=out0 if r == 0 else subprocess.DEVNULL))
+    deadline = time.monotonic() + a.rank_timeout if a.rank_timeout > 0 else None
+    why = None
+    while True:
+        codes = [p.poll() for p in procs]
+        bad = [(r, c) for r, c in enumerate(codes) if c not in (None, 0)]
+        if bad:
+            why = "rank(s) failed (rank, exit code): %s" % bad
+            break
+        if all(c == 0 for c in codes):
+            break
+        if deadline is not None and time.monotonic() > deadline:
+            why = "rank(s) failed: no result within --rank-timeout %.0f s (still running: %s)" % (
+                a.rank_timeout, [r for r, c in enumerate(codes) if c is None])
+            break
+        time.sleep(0.2)
+    if why:
+        for p in procs:                                   # exactly the children started above, by handle
+            if p.poll() is None:
+                p.terminate()
+        t_end = time.monotonic() + 5.0
+        for p in procs:
+            try:
+                p.wait(timeout=max(0.1, t_end - time.monotonic()))
+            except subprocess.TimeoutExpired:
+                p.kill()
+                p.wait()
+    out0.seek(0)
+    sys.stdout.write(out0.read().decode())
     sys.stdout.flush()
-    bad = [(r, c) for r, c in enumerate(codes) if c != 0]
-    if bad:
-        sys.stderr.write("bench.py: rank(s) failed (rank, exit code): %s\n" % bad)
+    if why:
+        sys.stderr.write("bench.py: %s\n" % why)
         return 1
     return 0
 
@@ -235,10 +270,16 @@ def main(argv=None):
     elif int(os.environ["WORLD_SIZE"]) != a.gpus and not a.force_dist:
         sys.stderr.write("bench.py: --gpus %d but the launcher started WORLD_SIZE=%s ranks\n" % (a.gpus, os.environ["WORLD_SIZE"]))
         return 2
-    _rank_imports()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.debug_fail_rank == rank and world > 1:
+        sys.stderr.write("bench.py: rank %d: --debug-fail-rank\n" % rank)
+        return 3
+    if a.debug_hang_rank == rank and world > 1:
+        import time
+        time.sleep(3600)
+    _rank_imports()
     dist = None
     if a.share_device0:
         local = 0

@@ -251,3 +251,31 @@ def test_bench_gpus_n_without_a_launcher_starts_n_ranks(lib_built):
     assert line["frames_per_s"] > 0 and line["status_flags"] == 0
     audio_per_step = 2 * 4 * (98 * 160 + 240) / 16000.0                  # both ranks' clips, trimmed to 98 frames
     assert abs(line["value"] * line["ms_per_step"] * 1e-3 - audio_per_step) < 1e-6 * audio_per_step
+
+
+def test_bench_eight_ranks_on_one_device_and_a_rank_that_dies(lib_built):
+    """Rehearsal of the 8-GPU launch the driver makes (`python bench.py --gpus 8`): eight rank processes, eight engines
+    (small workspaces: all on device 0, the all-gather over gloo), one JSON line that counts all eight ranks' clips --
+    and the same launch with rank 3 dying at start-up comes back as exit code 1 within seconds instead of hanging in
+    the other ranks' init_process_group."""
+    import json
+    import time
+    ctx = mp.get_context("forkserver")
+    q = ctx.Queue()
+    argv = ["--gpus", "8", "--share-device0", "--clips-per-gpu", "2", "--seconds", "1", "--steps", "1", "--warmup", "1",
+            "--frames-per-chunk", "196", "--no-kernel-pass", "--no-cpu-baseline", "--no-ceiling"]
+    p = ctx.Process(target=_bench_launcher, args=(argv, q))
+    p.start()
+    rc, out = q.get(timeout=1500)
+    p.join(timeout=60)
+    assert rc == 0, out
+    line = json.loads([ln for ln in out.splitlines() if ln.startswith("{")][0])
+    assert line["n_gpus"] == 8 and line["config"]["clips_per_gpu"] == 2 and line["status_flags"] == 0
+    audio_per_step = 8 * 2 * (98 * 160 + 240) / 16000.0
+    assert abs(line["value"] * line["ms_per_step"] * 1e-3 - audio_per_step) < 1e-6 * audio_per_step
+    t0 = time.time()
+    p = ctx.Process(target=_bench_launcher, args=(argv + ["--debug-fail-rank", "3"], q))
+    p.start()
+    rc, out = q.get(timeout=600)
+    p.join(timeout=60)
+    assert rc == 1 and time.time() - t0 < 300, (rc, out)

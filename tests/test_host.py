@@ -440,6 +440,26 @@ def test_bench_gpus_flag_is_honoured_or_refused(monkeypatch, capfd):
     assert "rank(s) failed" in capfd.readouterr().err
 
 
+def test_bench_self_launcher_ends_the_siblings_of_a_dead_rank(monkeypatch, capfd):
+    """bench.py --gpus N without a launcher polls ALL its children: when one rank dies (here rank 2, at start-up) while
+    another would sit in communicator initialisation for ever (rank 0 sleeps), the rest is terminated and the launcher
+    returns 1 within seconds; a job that produces nothing within --rank-timeout ends the same way."""
+    import sys
+    import time
+    sys.path.insert(0, ROOT)
+    import bench
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        monkeypatch.delenv(k, raising=False)
+    t0 = time.time()
+    assert bench.main(["--gpus", "3", "--debug-fail-rank", "2", "--debug-hang-rank", "0"]) == 1
+    err = capfd.readouterr().err
+    assert "rank(s) failed" in err and "(2, 3)" in err and time.time() - t0 < 30
+    t0 = time.time()
+    assert bench.main(["--gpus", "2", "--debug-hang-rank", "0", "--debug-fail-rank", "-1", "--rank-timeout", "2"]) == 1
+    err = capfd.readouterr().err
+    assert "rank(s) failed" in err and time.time() - t0 < 60
+
+
 # ------------------------------------------------------------------------------ Winograd folding (conv_wino.hip)
 def test_winograd_matrices_are_exact_and_match_the_kernel_constants():
     """fold.wino_matrices: Cook-Toom F(5,4) / F(6,3) on the points 0, +-1, +-2, +-1/2, infinity in exact rationals;
