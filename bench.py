@@ -277,7 +277,6 @@ def main(argv=None):
         sys.stderr.write("bench.py: rank %d: --debug-fail-rank\n" % rank)
         return 3
     if a.debug_hang_rank == rank and world > 1:
-        import time
         time.sleep(3600)
     _rank_imports()
     dist = None
