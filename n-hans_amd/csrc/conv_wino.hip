@@ -290,22 +290,29 @@ __global__ void __launch_bounds__(XW * 64) conv_wino(const ConvArgs a) {
               "v"(a0_), "v"(a1_), "n"(X_PLANE * 4) : "memory");                                    \
     }
 
-    // ---- prologue: tiles 0..2 and the weights of chunk 0 requested (tile 0 first: everybody waits for it), V of
-    // chunk 0 transformed by all eight waves ----
-    X_DMA(0, 0)
-    __builtin_amdgcn_sched_barrier(0);
-    X_LOAD_B(0)
-    __builtin_amdgcn_sched_barrier(0);
-    X_DMA(1, 1)
-    X_DMA(2, 2)
+    // ---- prologue: ONLY tile 0 is requested at entry -- everybody waits for it, and with tiles 1, 2 and the weights
+    // requested beside it (139 KB per CU in one burst) it landed after 10.5 k cycles: the CU's memory path serves
+    // requests in order --; the weights of chunk 0 and tile 1 follow from inside the transform of chunk 0 (all eight
+    // waves), tile 2 behind it ----
+    long long dbg_pre = 0, dbg_mid = 0;
+    if constexpr (DBG) dbg_pre = (long long)__builtin_amdgcn_s_memtime() - dbg_entry;
+    if constexpr (DBG) {
+        X_DMA2(0, 0, 0)
+        dbg_mid = (long long)__builtin_amdgcn_s_memtime() - dbg_entry;
+        X_DMA2(0, 0, 2)
+    } else {
+        X_DMA(0, 0)
+    }
     long long dbg_setup = 0;
     if constexpr (DBG) dbg_setup = (long long)__builtin_amdgcn_s_memtime() - dbg_entry;
-    asm volatile("s_waitcnt vmcnt(16)" ::: "memory");                   // tile 0 (behind it: 8 weight loads, 2 x 4 DMA)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     long long dbg_landed = 0;
     if constexpr (DBG) dbg_landed = (long long)__builtin_amdgcn_s_memtime() - dbg_entry;
-    X_TRANSFORM(0, 0, 0, 0, 0, true, 0)
-    asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");         // tile 1
+    X_TRANSFORM(0, 0, 0, 1, 1, true, 1)
+    __builtin_amdgcn_sched_barrier(0);
+    X_DMA(2, 2)
+    asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");         // tile 1 (in flight: weights 0 (8) | tile 1 (4) | tile 2 (4))
     __builtin_amdgcn_s_barrier();
 
     // ---- K loop.  Period c (between two barriers): every wave multiplies chunk c, transforms its share of chunk
@@ -395,8 +402,8 @@ __global__ void __launch_bounds__(XW * 64) conv_wino(const ConvArgs a) {
             long long* e = a.dbg + (size_t)(4 << 20) + ((size_t)blockIdx.x * 12 + wave) * 8;
             // setup | first tile landed | epilogue pass 0: M tiles in LDS, barrier passed, transform done (from the loop's end) | multiply | request + transform | wait for the tile
             e[0] = dbg_setup; e[1] = dbg_landed; e[2] = es[0] - dbg_t1; e[3] = es[1] - dbg_t1; e[4] = es[2] - dbg_t1; e[5] = dbg_mult; e[6] = dbg_xf; e[7] = dbg_wait;
-            long long* f = a.dbg + (size_t)(6 << 20) + ((size_t)blockIdx.x * 12 + wave) * 2;   // transform: reads landed | arithmetic done (from its start)
-            f[0] = dbg_ts[0]; f[1] = dbg_ts[1];
+            long long* f = a.dbg + (size_t)(6 << 20) + ((size_t)blockIdx.x * 12 + wave) * 4;   // transform: reads landed | arithmetic done (from its start) | entry -> first request
+            f[0] = dbg_ts[0]; f[1] = dbg_ts[1]; f[2] = dbg_pre; f[3] = dbg_mid;
         }
     }
 }

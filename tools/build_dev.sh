@@ -9,5 +9,5 @@ for f in conv_igemm conv_igemm_dma conv_igemm_halo conv_wino aux_kernels stft mf
   fi
 done
 wait
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o /root/repo/bin_tmp/libnhans_hip_dev.so /root/repo/bin_tmp/dev/*.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o /root/repo/bin_tmp/libnhans_hip_dev.so $(for f in conv_igemm conv_igemm_dma conv_igemm_halo conv_wino aux_kernels stft mfma_ceiling launch_status nhans_api; do echo /root/repo/bin_tmp/dev/$f.o; done)
 ls -la /root/repo/bin_tmp/libnhans_hip_dev.so

@@ -7,7 +7,8 @@
 // region (L2 hits), 1: every wave walks its own 4 MB window of a 8 GB buffer (HBM), 2: 70 % shared + 30 % private
 // (the kernel's mix), 3: as 0 through LDS-DMA (global_load_lds) instead of into registers, 4: the 70 / 30 mix with
 // the two streams in DIFFERENT waves (waves 0-5 shared with 14 iterations for every 18 of waves 6-7, private): do an
-// L2-hit stream and an HBM stream overlap inside one CU when no wave's in-order return couples them?
+// L2-hit stream and an HBM stream overlap inside one CU when no wave's in-order return couples them?  5: as 1 through
+// LDS-DMA.
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <vector>
@@ -34,7 +35,7 @@ __global__ void __launch_bounds__(512) k(const float* shared_src, const float* p
             const bool use_shared = MODE == 0 || MODE == 3 || (MODE == 2 && ((it * DEPTH + d) % 10) < 7) || (MODE == 4 && wave < 6);
             const char* p = use_shared ? sp + so : pp + po;
             if (use_shared) so = (so + 8192u) & smask; else po = (po + 1024u) & ((4u << 20) - 1u);
-            if constexpr (MODE == 3) {
+            if constexpr (MODE == 3 || MODE == 5) {
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)p,
                                                  (__attribute__((address_space(3))) void*)(smem + (wave * DEPTH + d) * 256), 16, 0, 0);
             } else {
@@ -45,7 +46,7 @@ __global__ void __launch_bounds__(512) k(const float* shared_src, const float* p
         __builtin_amdgcn_sched_barrier(0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
-        if constexpr (MODE != 3) {
+        if constexpr (MODE != 3 && MODE != 5) {
 #pragma unroll
             for (int d = 0; d < DEPTH; ++d) acc += r[d];
         }
@@ -103,6 +104,9 @@ int main() {
     run<8, 2>(s, p, 512, cyc, sink, "70 % shared + 30 % private");
     run<16, 2>(s, p, 512, cyc, sink, "70 % shared + 30 % private");
     run<32, 2>(s, p, 512, cyc, sink, "70 % shared + 30 % private");
+    run<4, 5>(s, p, 512, cyc, sink, "private (HBM) -> LDS (DMA)");
+    run<8, 5>(s, p, 512, cyc, sink, "private (HBM) -> LDS (DMA)");
+    run<16, 5>(s, p, 512, cyc, sink, "private (HBM) -> LDS (DMA)");
     run<8, 4>(s, p, 512, cyc, sink, "the same mix, streams in separate waves");
     run<16, 4>(s, p, 512, cyc, sink, "the same mix, streams in separate waves");
     run<32, 4>(s, p, 512, cyc, sink, "the same mix, streams in separate waves");

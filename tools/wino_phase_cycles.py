@@ -1,7 +1,6 @@
 """Dev tool: where a workgroup of the Winograd conv kernel (conv_wino.hip) spends its cycles, from s_memtime stamps of
 every wave (option debug_cycles_ptr; needs a developer build: `make -C n-hans_amd/csrc clean && make -C n-hans_amd/csrc DEV=1`):
-    python tools/wino_phase_cycles.py [block 1|3] [frames] [winograd 1|2]
-(1 = conv_wino.hip: 8 consumer + 4 producer waves; 2 = conv_wino128.hip: 8 waves that multiply and transform)"""
+    python tools/wino_phase_cycles.py [block 1|3] [frames]"""
 import os
 import sys
 
@@ -18,9 +17,8 @@ from nhans_amd.apply import normalise, trim_to_frames  # noqa: E402
 def main():
     block = int(sys.argv[1]) if len(sys.argv) > 1 else 1
     frames = int(sys.argv[2]) if len(sys.argv) > 2 else 998
-    wino = int(sys.argv[3]) if len(sys.argv) > 3 else 2
     eng = engine.Engine("denoiser", precision="f16x3")
-    eng.set_option("winograd", wino)
+    eng.set_option("winograd", 1)
     mix = trim_to_frames(normalise(synth.mixture(0, max(10.0, frames / 100.0 + 0.1))))
     lm, _ = eng.stft_features(torch.from_numpy(mix).cuda(), [0, len(mix)])
     ea = torch.zeros(1, 512, device="cuda")
@@ -40,36 +38,20 @@ def main():
     nblk = int((d[:, 0, 0] > 0).sum())
     d = d[:nblk]
     m = d.mean(0)
-    nc = g["cout"] // 16
     e = raw[(4 << 20):(4 << 20) + nblk * 96].reshape(nblk, 12, 8).astype(np.float64).mean(0)
-    if wino == 2:
-        nc = g["cout"] // 8
-        print("block %d conv2 (the last launch), %d workgroups, %d periods of 8 channels; MFMA floor per period %d cycles (per 128 tile-pixels)"
-              % (block, nblk, nc, 2 * 48 * 32))
-        print("  profile:", {k: round(v["ms"], 3) for k, v in prof.items() if "wino" in k or "halo" in k})
-        f = raw[(6 << 20):(6 << 20) + nblk * 24].reshape(nblk, 12, 2).astype(np.float64).mean(0)
-        for w in range(8):
-            print("  wave %d: transform per period: requests %.0f, tile reads landed %.0f, arithmetic done %.0f, writes drained %.0f"
-                  % (w, 0, f[w, 0] / (nc - 1), f[w, 1] / (nc - 1), e[w, 6] / nc))
-        for w in range(8):
-            print("  wave %d: setup %.0f, first tile %.0f, prologue %.0f | K loop %.0f = %.0f per period: multiply %.0f, request + transform %.0f, "
-                  "tile wait %.0f, barrier %.0f | epilogue %.0f (pass 0: tiles in LDS %.0f, barrier %.0f, transformed %.0f)"
-                  % (w, e[w, 0], e[w, 1], m[w, 1], m[w, 0], m[w, 0] / nc, e[w, 5] / nc, e[w, 6] / nc, e[w, 7] / nc, m[w, 3] / nc, m[w, 2],
-                     e[w, 2], e[w, 3], e[w, 4]))
-        return
-    print("block %d conv2 (the last launch), %d workgroups, %d chunks of 16 channels x %d filter rows; MFMA floor per chunk %d cycles"
-          % (block, nblk, nc, g["kh"], g["kh"] * 12 * 32 * 2))
+    nc = g["cout"] // 8
+    print("block %d conv2 (the last launch), %d workgroups, %d periods of 8 channels; MFMA floor per period %d cycles (per 128 tile-pixels)"
+          % (block, nblk, nc, 2 * 48 * 32))
     print("  profile:", {k: round(v["ms"], 3) for k, v in prof.items() if "wino" in k or "halo" in k})
-    for w in (0, 3, 7):
-        print("  consumer wave %d: waits for the first V %.0f | K loop %.0f (%.0f per chunk, of which barrier wait %.0f) | epilogue %.0f"
-              % (w, m[w, 1], m[w, 0], m[w, 0] / nc, m[w, 3] / nc, m[w, 2]))
-    for w in (0, 7):
-        print("  consumer wave %d: setup %.0f | epilogue, cycles from its start: M tiles in LDS %.0f | barrier passed %.0f | first pass stored "
-              "%.0f | all stores issued %.0f | drained %.0f" % (w, e[w, 0], e[w, 1], e[w, 2], e[w, 3], e[w, 4], e[w, 5]))
-    print("  producer wave 8: setup %.0f | first raw tile landed %.0f (from kernel entry)" % (e[8, 0], e[8, 1]))
-    for w in range(8, 12):
-        print("  producer wave %d: alive %.0f | first chunk (load + transform) %.0f | later chunks %.0f each | barrier wait %.0f per chunk"
-              % (w, m[w, 0], m[w, 1], m[w, 2] / max(nc - 1, 1), m[w, 3] / nc))
+    f = raw[(6 << 20):(6 << 20) + nblk * 48].reshape(nblk, 12, 4).astype(np.float64).mean(0)
+    for w in range(8):
+        print("  wave %d: transform per period: tile reads landed %.0f, arithmetic done %.0f, writes drained %.0f"
+              % (w, f[w, 0] / (nc - 1), f[w, 1] / (nc - 1), e[w, 6] / nc))
+    for w in range(8):
+        print("  wave %d: first request after %.0f, two of four issued %.0f, setup %.0f, first tile %.0f, prologue %.0f | K loop %.0f = %.0f per period: multiply %.0f, request + transform %.0f, "
+              "tile wait %.0f, barrier %.0f | epilogue %.0f (pass 0: tiles in LDS %.0f, barrier %.0f, transformed %.0f)"
+              % (w, f[w, 2], f[w, 3], e[w, 0], e[w, 1], m[w, 1], m[w, 0], m[w, 0] / nc, e[w, 5] / nc, e[w, 6] / nc, e[w, 7] / nc, m[w, 3] / nc, m[w, 2],
+                 e[w, 2], e[w, 3], e[w, 4]))
 
 
 if __name__ == "__main__":
