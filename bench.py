@@ -44,7 +44,7 @@ F16_MFMA_AT_POWER_CAP_TFLOPS = 1660.0   # round-2 measurement on another box (pr
                                         # --no-ceiling skips the live measurement (nhans_debug_mfma_ceiling) on THIS box
 HBM_PEAK_GBS = 8000.0             # spec; 6,290 GB/s is what a float4 copy achieves (same guide)
 HBM_ACHIEVABLE_GBS = 6290.0
-PMC_SUMMARY = os.path.join("profiles", "r03", "pmc_summary_bench_256clips.json")
+PMC_SUMMARY = os.path.join("profiles", "r04", "pmc_summary_bench_256clips.json")
 
 
 def parse(argv=None):
@@ -373,19 +373,28 @@ def main(argv=None):
         # FLOPs the matrix cores executed: 3 f16 products per MAC in split mode, and 2.5 x fewer MACs than the direct
         # form for the convs that run as 1-D Winograd (the library counts them per launch)
         exec_tflops = sum(v.get("mfma_flops", 0.0) for v in convs.values()) / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
-        # HBM bytes per conv launch: PMC counters cannot be read from inside this process; the committed
-        # summary of the separate rocprofv3 --pmc passes over this very command (profiles/r03/README.md) is
-        # quoted when the workload is the one it was collected on.
+        # HBM bytes per conv launch: PMC counters cannot be read from inside this process; the committed summary of the
+        # separate rocprofv3 --pmc passes over this very command (profiles/r04/README.md) is quoted when the workload is
+        # the one it was collected on AND the kernel sources are the ones it was collected from (the summary carries a
+        # fingerprint of n-hans_amd/csrc + fold.py, tools/pmc_summary.py): a kernel change makes `traffic` null instead of
+        # silently stale
         traffic, traffic_src = None, None
         pmc = os.path.join(ROOT, PMC_SUMMARY)
         if (a.precision == "f16x3" and a.clips_per_gpu == 256 and a.seconds == 10.0 and a.kind == "denoiser"
                 and os.path.exists(pmc)):
-            rows = [v for k, v in json.load(open(pmc)).items() if "conv_igemm" in k or "conv_wino" in k]
-            n = sum(v.get("dispatches_pass_c", 0) for v in rows)
-            if n:
-                traffic = sum((v.get("derived_hbm_read_bytes_per_launch", 0.0) + v.get("derived_hbm_write_bytes_per_launch", 0.0))
-                              * v.get("dispatches_pass_c", 0) for v in rows) / n
-                traffic_src = PMC_SUMMARY + " (FETCH_SIZE x2 + WRITE_SIZE, bytes per conv launch)"
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            from pmc_summary import kernel_source_sha16
+            summary = json.load(open(pmc))
+            meta = summary.pop("_meta", {})
+            if meta.get("kernel_source_sha16") != kernel_source_sha16(ROOT):
+                traffic_src = "%s is of other kernel sources (%s): not quoted" % (PMC_SUMMARY, meta.get("commit") or meta.get("kernel_source_sha16"))
+            else:
+                rows = [v for k, v in summary.items() if "conv_igemm" in k or "conv_wino" in k]
+                n = sum(v.get("dispatches_pass_c", 0) for v in rows)
+                if n:
+                    traffic = sum((v.get("derived_hbm_read_bytes_per_launch", 0.0) + v.get("derived_hbm_write_bytes_per_launch", 0.0))
+                                  * v.get("dispatches_pass_c", 0) for v in rows) / n
+                    traffic_src = "%s (FETCH_SIZE x2 + WRITE_SIZE, bytes per conv launch; commit %s)" % (PMC_SUMMARY, meta.get("commit"))
         gbs = lambda e: e["bytes"] / (e["ms"] * 1e-3) / 1e9 if e and e["ms"] > 0 else None
         # stft_features = the mixture's STFT (log-magnitude + phase: the 2,248 B/frame of SURVEY 8d); the two
         # context STFTs (200 frames per clip, log-magnitude only: 1,444 B/frame) are timed as their own entry
