@@ -187,7 +187,7 @@ __global__ void __launch_bounds__(XW * 64) conv_wino(const ConvArgs a) {
                   "=&v"(rl_[0]), "=&v"(rl_[1]), "=&v"(rl_[2]), "=&v"(rl_[3]), "=&v"(rl_[4]), "=&v"(rl_[5]), "=&v"(rl_[6]), "=&v"(rl_[7]) \
                 : "v"(rs_), "n"(X_RKIND * 4) : "memory");                                          \
         X_TSTAMP(0)                                                                                \
-        if (REQ) X_LOAD_B2(0, 0, u_)                                                                      \
+        if ((REQ) == 2) X_LOAD_B2(0, 0, u_)                                                        \
         uint2 oh_[8], ol_[8];                                                                      \
         _Pragma("unroll") for (int ep = 0; ep < 2; ++ep) {                                         \
             float d0_[8], d1_[8], v0_[8], v1_[8];                                                  \
@@ -197,7 +197,7 @@ __global__ void __launch_bounds__(XW * 64) conv_wino(const ConvArgs a) {
                 d1_[x] = unsplit_mix<1>(hp_, lp_);                                                 \
             }                                                                                      \
             __builtin_amdgcn_sched_barrier(0);                                                     \
-            if (REQ) { if (ep == 0) { X_LOAD_B2(0, 1, u_) } else { X_DMA2(DC, DB, 0) } }           \
+            if (ep == 0) { if ((REQ) == 2) X_LOAD_B2(0, 1, u_) } else if (REQ) { X_DMA2(DC, DB, 0) }  \
             __builtin_amdgcn_sched_barrier(0);                                                     \
             X_BT(d0_, v0_)                                                                         \
             X_BT(d1_, v1_)                                                                         \
@@ -252,42 +252,50 @@ __global__ void __launch_bounds__(XW * 64) conv_wino(const ConvArgs a) {
 #define X_LOAD_B2(S, J, UPTR)                                                                      \
     asm volatile("global_load_dwordx4 %0, %2, %3 offset:%4\n global_load_dwordx4 %1, %2, %3 offset:%4+1024" \
                  : "=&v"(fb[S][J][0]), "=&v"(fb[S][J][1]) : "v"((S) ? ub_hi : ub_lo), "s"(UPTR), "n"((J) * 2048) : "memory");
-#define X_LOAD_B(CC)                                                                               \
+    // (k-step 1 of chunk CC: k-step 0 is requested inside the multiply block of the chunk before)
+#define X_LOAD_B1(CC)                                                                              \
     {                                                                                              \
         const int cc_ = (CC) < NC ? (CC) : NC - 1;                                                 \
         const char* u_ = ub_base + (size_t)cc_ * (KH / 2) * 4096;                                  \
-        X_LOAD_B2(0, 0, u_) X_LOAD_B2(0, 1, u_) X_LOAD_B2(1, 0, u_) X_LOAD_B2(1, 1, u_)            \
+        X_LOAD_B2(1, 0, u_) X_LOAD_B2(1, 1, u_)                                                    \
     }
     // The chunk's 8 steps (k-step s, m-tile t) of 6 MFMAs each as ONE asm block (see X_TRANSFORM for why): the V
     // fragments of step i + 2 are requested behind the first MFMA of step i (ring of three) -- one wave per SIMD
     // multiplies at a time, so its own MFMAs must cover its LDS latency --; an accumulator tile is used by every other
-    // MFMA (a dependent MFMA issued back to back would wait for the first one's 8 passes).
-    // operands: 0-7 acc[t][j]; 8-13 ring r = (hi %8+2r, lo %9+2r); 14-21 fb[s][j][h]; 22 / 23 LDS address of k-step 0 / 1
+    // MFMA (a dependent MFMA issued back to back would wait for the first one's 8 passes).  The four weight fragments
+    // of k-step 0 are dead after step 3: the NEXT chunk's are requested into them behind the second MFMA of steps 4-7
+    // (a third of the period's requests issued in the shadow of the wave's own MFMAs instead of in the burst behind
+    // them).
+    // operands: 0-7 acc[t][j]; 8-13 ring r = (hi %8+2r, lo %9+2r); 14-21 fb[s][j][h]; 22 / 23 LDS address of k-step
+    // 0 / 1; 24 plane stride; 25 / 26 lane offset / base of the next chunk's weights
     const unsigned a_addr = (unsigned)(aoff * 4);
 #define X_MF(ACC, B, A) "v_mfma_f32_32x32x16_f16 %" #ACC ", %" #B ", %" #A ", %" #ACC "\n"
-    // step: wait for the ring slot, first MFMA, request the fragments of step i + 2, five MFMAs
-#define X_STEP(WAIT, A0, A1, HI, LO, B0H, B0L, B1H, B1L, NEXT)                                     \
-    "s_waitcnt lgkmcnt(" #WAIT ")\n" X_MF(A0, B0H, LO) NEXT X_MF(A1, B1H, LO) X_MF(A0, B0L, HI) X_MF(A1, B1L, HI) X_MF(A0, B0H, HI) X_MF(A1, B1H, HI)
-#define X_MULTIPLY(VB)                                                                             \
+    // step: wait for the ring slot, first MFMA, request the fragments of step i + 2, second MFMA, (a weight request,) four MFMAs
+#define X_STEP(WAIT, A0, A1, HI, LO, B0H, B0L, B1H, B1L, NEXT, NEXTB)                              \
+    "s_waitcnt lgkmcnt(" #WAIT ")\n" X_MF(A0, B0H, LO) NEXT X_MF(A1, B1H, LO) NEXTB X_MF(A0, B0L, HI) X_MF(A1, B1L, HI) X_MF(A0, B0H, HI) X_MF(A1, B1H, HI)
+#define X_MULTIPLY(VB, CN)                                                                         \
     if (!(DBG && (a.wino_m >> 8 & 2))) {                                                           \
         f32x4 r0h, r0l, r1h, r1l, r2h, r2l;                                                        \
         const unsigned a0_ = a_addr + (unsigned)((VB) * X_VBUF * 4), a1_ = a0_ + (unsigned)(2 * TJ * 16); \
+        const int cn_ = (CN) < NC ? (CN) : NC - 1;                                                 \
+        const char* un_ = ub_base + (size_t)cn_ * (KH / 2) * 4096;                                 \
         asm volatile(                                                                              \
             "s_waitcnt vmcnt(4)\n"                  /* the weights (behind them: one tile's 4 DMA requests) */ \
             "ds_read_b128 %8, %22\n ds_read_b128 %9, %22 offset:%24\n"                             \
             "ds_read_b128 %10, %22 offset:512\n ds_read_b128 %11, %22 offset:512+%24\n"            \
-            X_STEP(2, 0, 1, 8, 9, 14, 15, 16, 17, "ds_read_b128 %12, %22 offset:1024\n ds_read_b128 %13, %22 offset:1024+%24\n") \
-            X_STEP(2, 2, 3, 10, 11, 14, 15, 16, 17, "ds_read_b128 %8, %22 offset:1536\n ds_read_b128 %9, %22 offset:1536+%24\n") \
-            X_STEP(2, 4, 5, 12, 13, 14, 15, 16, 17, "ds_read_b128 %10, %23\n ds_read_b128 %11, %23 offset:%24\n") \
-            X_STEP(2, 6, 7, 8, 9, 14, 15, 16, 17, "ds_read_b128 %12, %23 offset:512\n ds_read_b128 %13, %23 offset:512+%24\n") \
-            X_STEP(2, 0, 1, 10, 11, 18, 19, 20, 21, "ds_read_b128 %8, %23 offset:1024\n ds_read_b128 %9, %23 offset:1024+%24\n") \
-            X_STEP(2, 2, 3, 12, 13, 18, 19, 20, 21, "ds_read_b128 %10, %23 offset:1536\n ds_read_b128 %11, %23 offset:1536+%24\n") \
-            X_STEP(2, 4, 5, 8, 9, 18, 19, 20, 21, "")                                              \
-            X_STEP(0, 6, 7, 10, 11, 18, 19, 20, 21, "")                                            \
+            X_STEP(2, 0, 1, 8, 9, 14, 15, 16, 17, "ds_read_b128 %12, %22 offset:1024\n ds_read_b128 %13, %22 offset:1024+%24\n", "") \
+            X_STEP(2, 2, 3, 10, 11, 14, 15, 16, 17, "ds_read_b128 %8, %22 offset:1536\n ds_read_b128 %9, %22 offset:1536+%24\n", "") \
+            X_STEP(2, 4, 5, 12, 13, 14, 15, 16, 17, "ds_read_b128 %10, %23\n ds_read_b128 %11, %23 offset:%24\n", "") \
+            X_STEP(2, 6, 7, 8, 9, 14, 15, 16, 17, "ds_read_b128 %12, %23 offset:512\n ds_read_b128 %13, %23 offset:512+%24\n", "") \
+            X_STEP(2, 0, 1, 10, 11, 18, 19, 20, 21, "ds_read_b128 %8, %23 offset:1024\n ds_read_b128 %9, %23 offset:1024+%24\n", "global_load_dwordx4 %14, %25, %26\n") \
+            X_STEP(2, 2, 3, 12, 13, 18, 19, 20, 21, "ds_read_b128 %10, %23 offset:1536\n ds_read_b128 %11, %23 offset:1536+%24\n", "global_load_dwordx4 %15, %25, %26 offset:1024\n") \
+            X_STEP(2, 4, 5, 8, 9, 18, 19, 20, 21, "", "global_load_dwordx4 %16, %25, %26 offset:2048\n") \
+            X_STEP(0, 6, 7, 10, 11, 18, 19, 20, 21, "", "global_load_dwordx4 %17, %25, %26 offset:3072\n") \
             : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[1][0]), "+v"(acc[1][1]), "+v"(acc[2][0]), "+v"(acc[2][1]), "+v"(acc[3][0]), "+v"(acc[3][1]), \
-              "=&v"(r0h), "=&v"(r0l), "=&v"(r1h), "=&v"(r1l), "=&v"(r2h), "=&v"(r2l)               \
-            : "v"(fb[0][0][0]), "v"(fb[0][0][1]), "v"(fb[0][1][0]), "v"(fb[0][1][1]), "v"(fb[1][0][0]), "v"(fb[1][0][1]), "v"(fb[1][1][0]), "v"(fb[1][1][1]), \
-              "v"(a0_), "v"(a1_), "n"(X_PLANE * 4) : "memory");                                    \
+              "=&v"(r0h), "=&v"(r0l), "=&v"(r1h), "=&v"(r1l), "=&v"(r2h), "=&v"(r2l),              \
+              "+v"(fb[0][0][0]), "+v"(fb[0][0][1]), "+v"(fb[0][1][0]), "+v"(fb[0][1][1])           \
+            : "v"(fb[1][0][0]), "v"(fb[1][0][1]), "v"(fb[1][1][0]), "v"(fb[1][1][1]),              \
+              "v"(a0_), "v"(a1_), "n"(X_PLANE * 4), "v"(ub_lo), "s"(un_) : "memory");              \
     }
 
     // ---- prologue: ONLY tile 0 is requested at entry -- everybody waits for it, and with tiles 1, 2 and the weights
@@ -309,7 +317,7 @@ __global__ void __launch_bounds__(XW * 64) conv_wino(const ConvArgs a) {
     __builtin_amdgcn_s_barrier();
     long long dbg_landed = 0;
     if constexpr (DBG) dbg_landed = (long long)__builtin_amdgcn_s_memtime() - dbg_entry;
-    X_TRANSFORM(0, 0, 0, 1, 1, true, 1)
+    X_TRANSFORM(0, 0, 0, 1, 1, true, 2)
     __builtin_amdgcn_sched_barrier(0);
     X_DMA(2, 2)
     asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");         // tile 1 (in flight: weights 0 (8) | tile 1 (4) | tile 2 (4))
@@ -335,19 +343,19 @@ __global__ void __launch_bounds__(XW * 64) conv_wino(const ConvArgs a) {
         const bool more_ = c_ + 1 < NC && !(DBG && (a.wino_m >> 8 & 4));                          \
         long long tq_ = 0;                                                                         \
         if constexpr (DBG) tq_ = (long long)__builtin_amdgcn_s_memtime();                          \
-        if (early) X_MULTIPLY(VB)                                                                  \
+        if (early) X_MULTIPLY(VB, c_ + 1)                                                                \
         X_STAMP(dbg_mult)                                                                          \
         __builtin_amdgcn_sched_barrier(0);                                                         \
         __builtin_amdgcn_s_setprio(2);                                                             \
         if constexpr (DBG) dbg_tq = (long long)__builtin_amdgcn_s_memtime();                       \
-        X_TRANSFORM(rn_, VB ^ 1, c_ + 1, c_ + 3, rb3, more_, early)                                \
+        X_TRANSFORM(rn_, VB ^ 1, c_ + 1, c_ + 3, rb3, more_, (early ? 1 : 0))                                \
         __builtin_amdgcn_s_setprio(0);                                                             \
         X_STAMP(dbg_xf)                                                                            \
         __builtin_amdgcn_sched_barrier(0);                                                         \
         if (!early) {                                                                              \
-            X_MULTIPLY(VB)                                                                         \
+            X_MULTIPLY(VB, c_ + 1)                                                                 \
             X_STAMP(dbg_mult)                                                                      \
-            X_LOAD_B(c_ + 1)                                                                       \
+            X_LOAD_B1(c_ + 1)                                                                      \
             __builtin_amdgcn_sched_barrier(0);                                                     \
             X_DMA(c_ + 3, rb3)                                                                     \
         }                                                                                          \
@@ -371,7 +379,7 @@ __global__ void __launch_bounds__(XW * 64) conv_wino(const ConvArgs a) {
 #undef X_MULTIPLY
 #undef X_STEP
 #undef X_MF
-#undef X_LOAD_B
+#undef X_LOAD_B1
 #undef X_TRANSFORM
 #undef X_BT
 #undef X_DMA

@@ -62,6 +62,14 @@ def check_kernel(name, lines):
             r.update(range(int(mm.group(1)), int(mm.group(2)) + 1))
         return frozenset(r)
 
+    def mult_loads(b):
+        r = set()
+        for l in b[2]:
+            mm = re.search(r"global_load_dwordx4 v\[(\d+):(\d+)\]", l)
+            if mm:
+                r.update(range(int(mm.group(1)), int(mm.group(2)) + 1))
+        return frozenset(r)
+
     def mult_regs(b):
         used, vops = set(), set()
         for l in b[2]:
@@ -74,6 +82,8 @@ def check_kernel(name, lines):
     allw = set()
     for b in loads:
         allw |= load_regs(b)
+    for b in mults:
+        allw |= mult_loads(b)                              # (the next chunk's k-step 0 is requested inside the block)
     for b in mults:
         if "s_waitcnt vmcnt(4)" not in b[2][0]:
             errs.append("a multiply block does not open with s_waitcnt vmcnt(4)")
@@ -103,6 +113,8 @@ def check_kernel(name, lines):
         kind[b[0]] = ("load", load_regs(b), b)
     for b in mults:
         kind[b[0]] = ("mult", mult_regs(b)[0], b)
+        if mult_loads(b):
+            kind[b[1]] = ("load", mult_loads(b), b)        # its own requests, as an event at the end of the block
     skip = set()
     for b in loads + mults:
         skip.update(range(b[0], b[1] + 1))
