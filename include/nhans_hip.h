@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define NHANS_ABI_VERSION 3
+#define NHANS_ABI_VERSION 4
 
 #define NHANS_DENOISER 0   /* SN model: emb_a = positive context (--pos), emb_b = negative (--neg) */
 #define NHANS_SEPARATOR 1  /* SS model: emb_a = interferer  (--neg),      emb_b = target   (--pos) */
@@ -82,7 +82,9 @@ int64_t nhans_num_frames(int64_t nsamples);
 /* Build a context from the folded-weights blob produced by nhans_amd.fold.fold_weights()
  * (format documented in n-hans_amd/fold.py).  The blob is copied to the device.  If the blob carries split-f16
  * weights, the activation exponents are calibrated here on a built-in two-second signal (one small pass of the whole
- * path in f32 mode; see "calibrate"). */
+ * path in f32 mode; see "calibrate").  The blob's header carries the version of the packing conventions
+ * (fold.BLOB_VERSION, 2 since ABI 4); a blob of another version is refused with NHANS_EINVAL -- it would load and compute
+ * wrong results -- and the message says to fold the weights again. */
 int nhans_create(int model_kind, const void* folded_blob, size_t nbytes, int device_id, nhans_ctx** out);
 void nhans_destroy(nhans_ctx* ctx);
 

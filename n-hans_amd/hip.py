@@ -24,7 +24,7 @@ EXPORTS = [
 ]
 STATUS_SATURATED = 1
 NUM_ACTIVATIONS = 25
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 _lib = None
 
