@@ -272,7 +272,7 @@ def apply_batch(kind, jobs):
     calls; under `python -m torch.distributed.run` (WORLD_SIZE > 1) the JOB LIST is sharded over the
     ranks (job i -> rank floor(i*G/N), dist.py): each rank reads, converts and normalises only its
     own block of files and runs it on its own GPU, one all-gather reassembles the waveforms (a job
-    whose files could not be read travels as a zero-length entry) and rank 0 writes the files.
+    whose files could not be read travels as length -1, dist.gather_ragged) and rank 0 writes the files.
     Returns the number of clips written by this rank."""
     import torch
     from . import dist as nd
@@ -297,11 +297,11 @@ def apply_batch(kind, jobs):
             _owns_process_group = True
         gather_dev = eng.device if tdist.get_backend() == "nccl" else torch.device("cpu")
         # denoised and round trip travel in one tensor per clip: ONE data all-gather
-        local = [torch.zeros(0) if o is None else torch.from_numpy(np.concatenate(o)) for o in outs]
-        both = nd.gather_ragged([t.to(gather_dev) for t in local], len(jobs), gather_dev)
+        local = [None if o is None else torch.from_numpy(np.concatenate(o)).to(gather_dev) for o in outs]
+        both = nd.gather_ragged(local, len(jobs), gather_dev)
         if rank != 0:
             return 0
-        outs = [None if t.numel() == 0 else (t[:t.numel() // 2].cpu().numpy(), t[t.numel() // 2:].cpu().numpy())
+        outs = [None if t is None else (t[:t.numel() // 2].cpu().numpy(), t[t.numel() // 2:].cpu().numpy())
                 for t in both]
     written = 0
     for (_, _, _, save_to), o in zip(jobs, outs):

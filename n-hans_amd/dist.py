@@ -26,9 +26,11 @@ def shard(items, world, rank):
 
 
 def gather_ragged(local, n_total, device, group=None):
-    """local: list of 1-D float32 tensors (this rank's outputs, in order; a zero-length tensor stands
-    for a clip that produced nothing).  Returns the list of all n_total outputs in global order on
-    every rank.  Two collectives: the lengths, then ONE all-gather of data.
+    """local: list of 1-D float32 tensors (this rank's outputs, in order); an entry may be None -- an
+    item this rank skipped (unreadable files) -- and comes back as None on every rank: it travels as
+    length -1 in the lengths vector, so that an output that is legitimately EMPTY (a clip of 0 frames)
+    stays an empty tensor.  Returns the list of all n_total outputs in global order on every rank.
+    Two collectives: the lengths, then ONE all-gather of data.
 
     Each rank sends its clips back to back in one flat buffer, padded only to the largest per-rank
     TOTAL -- not every clip to the longest clip of the job: one ten-minute recording among thousands
@@ -39,12 +41,13 @@ def gather_ragged(local, n_total, device, group=None):
     per = max(hi - lo for lo, hi in bounds) if bounds else 0
     lens = torch.zeros(max(per, 1), dtype=torch.int64)
     for i, t in enumerate(local):
-        lens[i] = t.numel()
+        lens[i] = -1 if t is None else t.numel()
+    local = [t for t in local if t is not None and t.numel()]
     lens = lens.to(device)
     all_lens = torch.empty(world * max(per, 1), dtype=torch.int64, device=device)
     dist.all_gather_into_tensor(all_lens, lens, group=group)
     all_lens = all_lens.cpu().view(world, max(per, 1))          # the one device -> host read
-    rank_total = all_lens.sum(dim=1)
+    rank_total = all_lens.clamp(min=0).sum(dim=1)
     width = int(rank_total.max()) if n_total else 0
     flat = torch.zeros(max(width, 1), dtype=torch.float32, device=device)
     if local:
@@ -57,6 +60,9 @@ def gather_ragged(local, n_total, device, group=None):
         at = 0
         for j in range(hi - lo):
             n = int(all_lens[r, j])
+            if n < 0:
+                res.append(None)
+                continue
             res.append(out[r, at:at + n])
             at += n
     return res

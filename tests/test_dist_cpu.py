@@ -48,9 +48,10 @@ def _worker(rank, world, port, q):
     out1 = nd.enhance_sharded(_fake_enhance, mixes[:1], ca[:1], cb[:1], torch.device("cpu"))
     ok = ok and len(out1) == 1 and torch.equal(out1[0], ref[0])
     # one long recording among short ones: the data all-gather carries each rank's clips back to back, padded to the
-    # largest per-rank TOTAL (not every clip to the longest clip), and a zero-length entry (skipped job) survives
-    lens2 = [400, 100000, 0, 400, 560, 400]
-    loc = [torch.full((n,), float(i + 1)) for i, n in enumerate(lens2)]
+    # largest per-rank TOTAL (not every clip to the longest clip); an EMPTY output (a clip of 0 frames) comes back as an
+    # empty tensor and a skipped job (None: length -1 on the wire) as None -- the two are not the same thing
+    lens2 = [400, 100000, 0, 400, None, 400]
+    loc = [None if n is None else torch.full((n,), float(i + 1)) for i, n in enumerate(lens2)]
     lo, hi = nd.shard_bounds(len(lens2), world, rank)
     sizes = []
     real = dist.all_gather_into_tensor
@@ -63,7 +64,8 @@ def _worker(rank, world, port, q):
         got = nd.gather_ragged(loc[lo:hi], len(lens2), torch.device("cpu"))
     finally:
         nd.dist.all_gather_into_tensor = real
-    ok = ok and [t.numel() for t in got] == lens2 and all(torch.equal(a, b) for a, b in zip(got, loc))
+    ok = ok and [None if t is None else t.numel() for t in got] == lens2
+    ok = ok and all((a is None and b is None) or torch.equal(a, b) for a, b in zip(got, loc))
     ok = ok and sizes == [world * 3, world * (400 + 100000 + 0)]            # lengths, then data: 2 x 100,400, not 6 x 100,000
     q.put((rank, ok))
     dist.destroy_process_group()
