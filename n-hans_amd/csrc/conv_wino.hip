@@ -252,12 +252,23 @@ __global__ void __launch_bounds__(XW * 64) conv_wino(const ConvArgs a) {
 #define X_LOAD_B2(S, J, UPTR)                                                                      \
     asm volatile("global_load_dwordx4 %0, %2, %3 offset:%4\n global_load_dwordx4 %1, %2, %3 offset:%4+1024" \
                  : "=&v"(fb[S][J][0]), "=&v"(fb[S][J][1]) : "v"((S) ? ub_hi : ub_lo), "s"(UPTR), "n"((J) * 2048) : "memory");
+    // the same, skipped (uniformly) when SKIP != 0: the registers keep their values
+#define X_LOAD_B2C(S, J, UPTR, SKIP)                                                               \
+    asm volatile("s_cmp_eq_u32 %5, 0\n s_cbranch_scc0 1f\n"                                        \
+                 "global_load_dwordx4 %0, %2, %3 offset:%4\n global_load_dwordx4 %1, %2, %3 offset:%4+1024\n1:" \
+                 : "+v"(fb[S][J][0]), "+v"(fb[S][J][1]) : "v"((S) ? ub_hi : ub_lo), "s"(UPTR), "n"((J) * 2048), "s"((int)(SKIP)) : "memory", "scc");
     // (k-step 1 of chunk CC: k-step 0 is requested inside the multiply block of the chunk before)
 #define X_LOAD_B1(CC)                                                                              \
     {                                                                                              \
         const int cc_ = (CC) < NC ? (CC) : NC - 1;                                                 \
         const char* u_ = ub_base + (size_t)cc_ * (KH / 2) * 4096;                                  \
         X_LOAD_B2(1, 0, u_) X_LOAD_B2(1, 1, u_)                                                    \
+    }
+#define X_LOAD_B1C(CC, SKIP)                                                                       \
+    {                                                                                              \
+        const int cc_ = (CC) < NC ? (CC) : NC - 1;                                                 \
+        const char* u_ = ub_base + (size_t)cc_ * (KH / 2) * 4096;                                  \
+        X_LOAD_B2C(1, 0, u_, SKIP) X_LOAD_B2C(1, 1, u_, SKIP)                                      \
     }
     // The chunk's 8 steps (k-step s, m-tile t) of 6 MFMAs each as ONE asm block (see X_TRANSFORM for why): the V
     // fragments of step i + 2 are requested behind the first MFMA of step i (ring of three) -- one wave per SIMD
@@ -273,13 +284,14 @@ __global__ void __launch_bounds__(XW * 64) conv_wino(const ConvArgs a) {
     // step: wait for the ring slot, first MFMA, request the fragments of step i + 2, second MFMA, (a weight request,) four MFMAs
 #define X_STEP(WAIT, A0, A1, HI, LO, B0H, B0L, B1H, B1L, NEXT, NEXTB)                              \
     "s_waitcnt lgkmcnt(" #WAIT ")\n" X_MF(A0, B0H, LO) NEXT X_MF(A1, B1H, LO) NEXTB X_MF(A0, B0L, HI) X_MF(A1, B1L, HI) X_MF(A0, B0H, HI) X_MF(A1, B1H, HI)
-#define X_MULTIPLY(VB, CN)                                                                         \
+#define X_MULTIPLY(VB, CN, LAST)                                                                   \
     if (!(DBG && (a.wino_m >> 8 & 2))) {                                                           \
         f32x4 r0h, r0l, r1h, r1l, r2h, r2l;                                                        \
         const unsigned a0_ = a_addr + (unsigned)((VB) * X_VBUF * 4), a1_ = a0_ + (unsigned)(2 * TJ * 16); \
         const int cn_ = (CN) < NC ? (CN) : NC - 1;                                                 \
         const char* un_ = ub_base + (size_t)cn_ * (KH / 2) * 4096;                                 \
         asm volatile(                                                                              \
+            "s_cmp_eq_u32 %27, 0\n"                 /* scc = "another chunk follows": its k-step-0 weights are requested below */ \
             "s_waitcnt vmcnt(4)\n"                  /* the weights (behind them: one tile's 4 DMA requests) */ \
             "ds_read_b128 %8, %22\n ds_read_b128 %9, %22 offset:%24\n"                             \
             "ds_read_b128 %10, %22 offset:512\n ds_read_b128 %11, %22 offset:512+%24\n"            \
@@ -287,15 +299,15 @@ __global__ void __launch_bounds__(XW * 64) conv_wino(const ConvArgs a) {
             X_STEP(2, 2, 3, 10, 11, 14, 15, 16, 17, "ds_read_b128 %8, %22 offset:1536\n ds_read_b128 %9, %22 offset:1536+%24\n", "") \
             X_STEP(2, 4, 5, 12, 13, 14, 15, 16, 17, "ds_read_b128 %10, %23\n ds_read_b128 %11, %23 offset:%24\n", "") \
             X_STEP(2, 6, 7, 8, 9, 14, 15, 16, 17, "ds_read_b128 %12, %23 offset:512\n ds_read_b128 %13, %23 offset:512+%24\n", "") \
-            X_STEP(2, 0, 1, 10, 11, 18, 19, 20, 21, "ds_read_b128 %8, %23 offset:1024\n ds_read_b128 %9, %23 offset:1024+%24\n", "global_load_dwordx4 %14, %25, %26\n") \
-            X_STEP(2, 2, 3, 12, 13, 18, 19, 20, 21, "ds_read_b128 %10, %23 offset:1536\n ds_read_b128 %11, %23 offset:1536+%24\n", "global_load_dwordx4 %15, %25, %26 offset:1024\n") \
-            X_STEP(2, 4, 5, 8, 9, 18, 19, 20, 21, "", "global_load_dwordx4 %16, %25, %26 offset:2048\n") \
-            X_STEP(0, 6, 7, 10, 11, 18, 19, 20, 21, "", "global_load_dwordx4 %17, %25, %26 offset:3072\n") \
+            X_STEP(2, 0, 1, 10, 11, 18, 19, 20, 21, "ds_read_b128 %8, %23 offset:1024\n ds_read_b128 %9, %23 offset:1024+%24\n", "s_cbranch_scc0 1f\n global_load_dwordx4 %14, %25, %26\n1:\n") \
+            X_STEP(2, 2, 3, 12, 13, 18, 19, 20, 21, "ds_read_b128 %10, %23 offset:1536\n ds_read_b128 %11, %23 offset:1536+%24\n", "s_cbranch_scc0 1f\n global_load_dwordx4 %15, %25, %26 offset:1024\n1:\n") \
+            X_STEP(2, 4, 5, 8, 9, 18, 19, 20, 21, "", "s_cbranch_scc0 1f\n global_load_dwordx4 %16, %25, %26 offset:2048\n1:\n") \
+            X_STEP(0, 6, 7, 10, 11, 18, 19, 20, 21, "", "s_cbranch_scc0 1f\n global_load_dwordx4 %17, %25, %26 offset:3072\n1:\n") \
             : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[1][0]), "+v"(acc[1][1]), "+v"(acc[2][0]), "+v"(acc[2][1]), "+v"(acc[3][0]), "+v"(acc[3][1]), \
               "=&v"(r0h), "=&v"(r0l), "=&v"(r1h), "=&v"(r1l), "=&v"(r2h), "=&v"(r2l),              \
               "+v"(fb[0][0][0]), "+v"(fb[0][0][1]), "+v"(fb[0][1][0]), "+v"(fb[0][1][1])           \
             : "v"(fb[1][0][0]), "v"(fb[1][0][1]), "v"(fb[1][1][0]), "v"(fb[1][1][1]),              \
-              "v"(a0_), "v"(a1_), "n"(X_PLANE * 4), "v"(ub_lo), "s"(un_) : "memory");              \
+              "v"(a0_), "v"(a1_), "n"(X_PLANE * 4), "v"(ub_lo), "s"(un_), "s"((int)(LAST)) : "memory", "scc"); \
     }
 
     // ---- prologue: ONLY tile 0 is requested at entry -- everybody waits for it, and with tiles 1, 2 and the weights
@@ -343,21 +355,28 @@ __global__ void __launch_bounds__(XW * 64) conv_wino(const ConvArgs a) {
         const bool more_ = c_ + 1 < NC && !(DBG && (a.wino_m >> 8 & 4));                          \
         long long tq_ = 0;                                                                         \
         if constexpr (DBG) tq_ = (long long)__builtin_amdgcn_s_memtime();                          \
-        if (early) X_MULTIPLY(VB, c_ + 1)                                                                \
+        /* the last period requests nothing and transforms nothing: the waves that multiply second had sent twelve  */ \
+        /* dummy requests just before the loop's end, and the wait for them -- a memory latency under load, 6-7 k   */ \
+        /* cycles -- stood between the loop and the epilogue while the other four waited at the epilogue's barrier */ \
+        int last_;                                  /* (defined in a scalar register by construction: the "s" constraint alone does not move a value there) */ \
+        asm volatile("s_cmp_lg_u32 %1, 0\n s_cselect_b32 %0, 0, 1" : "=s"(last_) : "s"(__builtin_amdgcn_readfirstlane((int)more_)) : "scc"); \
+        if (early) X_MULTIPLY(VB, c_ + 1, last_)                                                   \
         X_STAMP(dbg_mult)                                                                          \
         __builtin_amdgcn_sched_barrier(0);                                                         \
-        __builtin_amdgcn_s_setprio(2);                                                             \
-        if constexpr (DBG) dbg_tq = (long long)__builtin_amdgcn_s_memtime();                       \
-        X_TRANSFORM(rn_, VB ^ 1, c_ + 1, c_ + 3, rb3, more_, (early ? 1 : 0))                                \
-        __builtin_amdgcn_s_setprio(0);                                                             \
+        if (more_) {                                                                               \
+            __builtin_amdgcn_s_setprio(2);                                                         \
+            if constexpr (DBG) dbg_tq = (long long)__builtin_amdgcn_s_memtime();                   \
+            X_TRANSFORM(rn_, VB ^ 1, c_ + 1, c_ + 3, rb3, true, (early ? 1 : 0))                   \
+            __builtin_amdgcn_s_setprio(0);                                                         \
+        }                                                                                          \
         X_STAMP(dbg_xf)                                                                            \
         __builtin_amdgcn_sched_barrier(0);                                                         \
         if (!early) {                                                                              \
-            X_MULTIPLY(VB, c_ + 1)                                                                 \
+            X_MULTIPLY(VB, c_ + 1, last_)                                                          \
             X_STAMP(dbg_mult)                                                                      \
-            X_LOAD_B1(c_ + 1)                                                                      \
+            X_LOAD_B1C(c_ + 1, last_)                                                              \
             __builtin_amdgcn_sched_barrier(0);                                                     \
-            X_DMA(c_ + 3, rb3)                                                                     \
+            if (more_) X_DMA(c_ + 3, rb3)                                                          \
         }                                                                                          \
         asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)" ::: "memory");                               \
         X_STAMP(dbg_wait)                                                                          \
@@ -370,7 +389,7 @@ __global__ void __launch_bounds__(XW * 64) conv_wino(const ConvArgs a) {
         X_PERIOD(c, 0)
         X_PERIOD(c + 1, 1)
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                    // (the tail's dummy requests: nothing may land in LDS later)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                    // (period NC - 2's dummy tile requests: nothing may land in LDS later)
     if constexpr (DBG) dbg_t1 = (long long)__builtin_amdgcn_s_memtime();
 #undef X_PERIOD
 #undef X_STAMP
@@ -380,18 +399,20 @@ __global__ void __launch_bounds__(XW * 64) conv_wino(const ConvArgs a) {
 #undef X_STEP
 #undef X_MF
 #undef X_LOAD_B1
+#undef X_LOAD_B1C
+#undef X_LOAD_B2C
 #undef X_TRANSFORM
 #undef X_BT
 #undef X_DMA
 #undef X_DMA2
 
     // ---- epilogue in two passes of 64 tile-pixels (the eight M_p tiles of a pass are 136 KB of LDS) ----
-    long long es[3] = {0, 0, 0};
+    long long es[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #define X_EPI(IDM)                                                                                 \
     {                                                                                              \
         wino_epilogue<IDM, MO>(a, acc, smem, p, lane, tid, b, nb, r0, j0, TR, TJ, cbx, DBG ? es : nullptr, 0, true); \
         __builtin_amdgcn_s_barrier();                                                              \
-        wino_epilogue<IDM, MO>(a, acc + 2, smem, p, lane, tid, b, nb, r0, j0, TR, TJ, cbx, nullptr, 64, false); \
+        wino_epilogue<IDM, MO>(a, acc + 2, smem, p, lane, tid, b, nb, r0, j0, TR, TJ, cbx, DBG ? es + 8 : nullptr, 64, false); \
     }
     switch (a.id_mode) {
         case 0: X_EPI(0) break;
@@ -412,6 +433,9 @@ __global__ void __launch_bounds__(XW * 64) conv_wino(const ConvArgs a) {
             e[0] = dbg_setup; e[1] = dbg_landed; e[2] = es[0] - dbg_t1; e[3] = es[1] - dbg_t1; e[4] = es[2] - dbg_t1; e[5] = dbg_mult; e[6] = dbg_xf; e[7] = dbg_wait;
             long long* f = a.dbg + (size_t)(6 << 20) + ((size_t)blockIdx.x * 12 + wave) * 4;   // transform: reads landed | arithmetic done (from its start) | entry -> first request
             f[0] = dbg_ts[0]; f[1] = dbg_ts[1]; f[2] = dbg_pre; f[3] = dbg_mid;
+            long long* h = a.dbg + (size_t)(8 << 20) + ((size_t)blockIdx.x * 12 + wave) * 16;  // epilogue, both passes, from the loop's end
+            for (int i = 0; i < 16; ++i) h[i] = es[i] ? es[i] - dbg_t1 : 0;
+            h[6] = t_end - dbg_t1;
         }
     }
 }

@@ -87,17 +87,28 @@ __device__ __forceinline__ void wino_epilogue(const ConvArgs& a, const f32x16 (*
     // cst: [ws | idw][64], then per block row r: bias + tt[r0 + r] (the time term of the position table rides in the bias
     // of the transform stage: v = fma(y, ws, bias + tt) + ff), fetched by the first tile-pixel of each row
     float* const cst = ct + 8 * 64 * W_LDM;
+    if (kDev && es) es[3] = (long long)__builtin_amdgcn_s_memtime();
+    // These eight requests are asm, and so is the wait for them further down: the compiler's count of what is in flight
+    // does not survive the two branches, and left to it the wait in front of the LDS stores of the constants was
+    // s_waitcnt vmcnt(0) -- every residual had to LAND before the barrier instead of under the exchange and the output
+    // transform.  (The compiler believes the registers valid from here on and inserts no wait of its own; nothing
+    // reads them before the hand-written one.)
     f32x4 ka[4], kb[4];
     const bool row_head = tt == 0 && rr < TR;
     const bool chan_head = q == 0 && first;
     if (chan_head) {
-        ka[0] = *reinterpret_cast<const f32x4*>(a.ws + n); ka[1] = *reinterpret_cast<const f32x4*>(a.ws + n + 4);
-        if constexpr (IDM != 0) { ka[2] = *reinterpret_cast<const f32x4*>(a.idw + n); ka[3] = *reinterpret_cast<const f32x4*>(a.idw + n + 4); }
+        const float* wsp = a.ws + n;
+        const float* idp = IDM != 0 ? a.idw + n : a.zero;
+        asm volatile("global_load_dwordx4 %0, %4, off\n global_load_dwordx4 %1, %4, off offset:16\n"
+                     "global_load_dwordx4 %2, %5, off\n global_load_dwordx4 %3, %5, off offset:16"
+                     : "=&v"(ka[0]), "=&v"(ka[1]), "=&v"(ka[2]), "=&v"(ka[3]) : "v"(wsp), "v"(idp) : "memory");
     }
     if (row_head) {
         const float* ttp = a.tt ? a.tt + (size_t)(ho < a.Ho ? ho : 0) * a.N + n : a.zero;
-        kb[0] = *reinterpret_cast<const f32x4*>(a.cb + cx + n); kb[1] = *reinterpret_cast<const f32x4*>(a.cb + cx + n + 4);
-        kb[2] = *reinterpret_cast<const f32x4*>(ttp); kb[3] = *reinterpret_cast<const f32x4*>(ttp + 4 * f_tf);
+        const float* cbp = a.cb + cx + n;
+        asm volatile("global_load_dwordx4 %0, %4, off\n global_load_dwordx4 %1, %4, off offset:16\n"
+                     "global_load_dwordx4 %2, %5, off\n global_load_dwordx4 %3, %5, off offset:16"
+                     : "=&v"(kb[0]), "=&v"(kb[1]), "=&v"(kb[2]), "=&v"(kb[3]) : "v"(cbp), "v"(ttp) : "memory");
     }
     __builtin_amdgcn_sched_barrier(0);
 
@@ -131,6 +142,7 @@ __device__ __forceinline__ void wino_epilogue(const ConvArgs& a, const f32x16 (*
         for (int i = 0; i < MO; ++i) rsv[i] = a.id[ids0 + (i < lastc ? i : lastc) * a.idsw];
     }
     __builtin_amdgcn_sched_barrier(0);
+    if (kDev && es) es[4] = (long long)__builtin_amdgcn_s_memtime();
 
     // 2. accumulators -> LDS.  Channel n = 8a + 4b + c of the 64 sits at float b*32 + a*4 + c of its row: the sweep
     // thread of channel group a reads two 16-byte pieces, and eight such threads cover 128 contiguous bytes each time
@@ -143,6 +155,10 @@ __device__ __forceinline__ void wino_epilogue(const ConvArgs& a, const f32x16 (*
                 const f32x4 v = {acc[t][j][4 * q4], acc[t][j][4 * q4 + 1], acc[t][j][4 * q4 + 2], acc[t][j][4 * q4 + 3]};
                 *reinterpret_cast<f32x4*>(ct + (p * 64 + t * 32 + (lane & 31)) * W_LDM + g8 * 32 + (j * 4 + q4) * 4) = v;
             }
+    // the constants have landed when at most the residual requests (younger, in order) are in flight
+    if constexpr (IDM == 1 || IDM == 2) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * MO) : "memory");
+    else if constexpr (IDM == 3) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(MO) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (chan_head) {
         const float in_scale = CONV_KARG(in_scale), id_scale = CONV_KARG(id_scale);
         *reinterpret_cast<f32x4*>(cst + c8 * 8) = ka[0] * in_scale; *reinterpret_cast<f32x4*>(cst + c8 * 8 + 4) = ka[1] * in_scale;
@@ -151,7 +167,7 @@ __device__ __forceinline__ void wino_epilogue(const ConvArgs& a, const f32x16 (*
         }
     }
     if (row_head) {
-        *reinterpret_cast<f32x4*>(cst + (2 + rr) * 64 + c8 * 8) = kb[0] + kb[2];
+        *reinterpret_cast<f32x4*>(cst + (2 + rr) * 64 + c8 * 8) = kb[0] + kb[2];           // (an absent table: 32 bytes of the zero page)
         *reinterpret_cast<f32x4*>(cst + (2 + rr) * 64 + c8 * 8 + 4) = kb[1] + kb[3];
     }
     if (kDev && es) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); es[0] = (long long)__builtin_amdgcn_s_memtime(); }
@@ -261,6 +277,7 @@ __device__ __forceinline__ void wino_epilogue(const ConvArgs& a, const f32x16 (*
         }
         __builtin_amdgcn_sched_barrier(0);                     // (column by column: bounded register pressure)
     }
+    if (kDev && es) es[5] = (long long)__builtin_amdgcn_s_memtime();
     int* const satp = CONV_KARG(sat);
     if (sat && satp) atomicOr(satp, kSatActivation);
 }

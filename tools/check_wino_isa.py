@@ -50,7 +50,11 @@ def check_kernel(name, lines):
             blocks.append(cur)
         elif inasm:
             cur[2].append(l)
-    loads = [b for b in blocks if b[2] and all("global_load_dwordx4" in l for l in b[2] if l.strip())]
+    # (a request block may be skipped as a whole: s_cmp / s_cbranch_scc0 to a local label in front of its loads)
+    def is_load_line(l):
+        t = l.strip()
+        return not t or "global_load_dwordx4" in t or t.startswith("s_cmp_") or t.startswith("s_cbranch_scc") or re.match(r"^\.?L?\w*\d+:$", t) is not None
+    loads = [b for b in blocks if b[2] and any("global_load_dwordx4" in l for l in b[2]) and all(is_load_line(l) for l in b[2])]
     mults = [b for b in blocks if any("v_mfma" in l for l in b[2])]
     if len(loads) < 3 or len(mults) < 4:
         return errs + ["expected >= 3 weight-request blocks and 4 multiply blocks, found %d / %d" % (len(loads), len(mults))]
@@ -59,7 +63,8 @@ def check_kernel(name, lines):
         r = set()
         for l in b[2]:
             mm = re.search(r"global_load_dwordx4 v\[(\d+):(\d+)\]", l)
-            r.update(range(int(mm.group(1)), int(mm.group(2)) + 1))
+            if mm:
+                r.update(range(int(mm.group(1)), int(mm.group(2)) + 1))
         return frozenset(r)
 
     def mult_loads(b):
@@ -85,7 +90,7 @@ def check_kernel(name, lines):
     for b in mults:
         allw |= mult_loads(b)                              # (the next chunk's k-step 0 is requested inside the block)
     for b in mults:
-        if "s_waitcnt vmcnt(4)" not in b[2][0]:
+        if not any("s_waitcnt vmcnt(4)" in l for l in b[2][:2]):
             errs.append("a multiply block does not open with s_waitcnt vmcnt(4)")
         w, v = mult_regs(b)
         if w & v:
@@ -144,6 +149,35 @@ def check_kernel(name, lines):
             errs.append("request at line %d: the next multiply block reads other registers" % i)
         for j, t in touched[:lastgood or 0]:
             errs.append("line %d touches a weight register between request and use: %s" % (j, t))
+    # the epilogue's constants: asm requests (64-bit address, "off"), then compiler-visible residual requests, then the
+    # hand-written s_waitcnt vmcnt(N): exactly N vector-memory instructions lie between the last constants block and
+    # the wait, and nothing in between mentions the constants' registers
+    consts = [b for b in blocks if b[2] and sum("global_load_dwordx4" in l and l.split(";")[0].rstrip().endswith(("off", "offset:16")) for l in b[2]) == 4]
+    waits = [b for b in blocks if len([l for l in b[2] if l.strip()]) == 1 and re.search(r"s_waitcnt vmcnt\(\d+\)\s*$", b[2][0])]
+    if len(consts) < 2:
+        errs.append("epilogue: constants request blocks not found")
+    for w in waits:
+        if w[0] < back[1]:
+            continue                                          # (the loop's own waits)
+        prev = [c for c in consts if c[1] < w[0]]
+        if not prev or w[0] - prev[-1][1] > 400:
+            continue
+        n = int(re.search(r"vmcnt\((\d+)\)", w[2][0]).group(1))
+        regs = set()
+        for c in prev[-2:]:
+            if w[0] - c[1] <= 400:
+                regs |= load_regs(c)
+        cnt, bad = 0, []
+        for i in range(prev[-1][1] + 1, w[0]):
+            code = lines[i].split(";")[0]
+            if re.match(r"\s*(global_|buffer_|scratch_|flat_)", code):
+                cnt += 1
+            if vgprs(code) & regs:
+                bad.append(lines[i].strip())
+        if cnt != n:
+            errs.append("epilogue: %d vector-memory instructions between the constants and s_waitcnt vmcnt(%d) (line %d)" % (cnt, n, w[0]))
+        for t in bad:
+            errs.append("epilogue: a constants register is touched before the wait: " + t)
     inasm = False
     for i in range(first, back[1] + 1):
         l = lines[i]

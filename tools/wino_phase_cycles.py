@@ -22,7 +22,7 @@ def main():
     mix = trim_to_frames(normalise(synth.mixture(0, max(10.0, frames / 100.0 + 0.1))))
     lm, _ = eng.stft_features(torch.from_numpy(mix).cuda(), [0, len(mix)])
     ea = torch.zeros(1, 512, device="cuda")
-    dbg = torch.zeros(8 * (1 << 20), dtype=torch.int64, device="cuda")
+    dbg = torch.zeros(12 * (1 << 20), dtype=torch.int64, device="cuda")
     eng.set_option("debug_cycles_ptr", dbg.data_ptr())
     eng.set_option("frames_per_chunk", frames)
     for _ in range(2):
@@ -52,6 +52,11 @@ def main():
               "tile wait %.0f, barrier %.0f | epilogue %.0f (pass 0: tiles in LDS %.0f, barrier %.0f, transformed %.0f)"
               % (w, f[w, 2], f[w, 3], e[w, 0], e[w, 1], m[w, 1], m[w, 0], m[w, 0] / nc, e[w, 5] / nc, e[w, 6] / nc, e[w, 7] / nc, m[w, 3] / nc, m[w, 2],
                  e[w, 2], e[w, 3], e[w, 4]))
+    h = raw[(8 << 20):(8 << 20) + nblk * 192].reshape(nblk, 12, 16).astype(np.float64).mean(0)
+    for w in range(8):
+        print("  wave %d epilogue from the loop's end: pass 0 entry %.0f, residual requested %.0f, tiles in LDS %.0f, barrier %.0f, transformed %.0f, columns stored %.0f | "
+              "pass 1 entry %.0f, requested %.0f, tiles %.0f, barrier %.0f, transformed %.0f, stored %.0f | drained %.0f"
+              % (w, h[w, 3], h[w, 4], h[w, 0], h[w, 1], h[w, 2], h[w, 5], h[w, 11], h[w, 12], h[w, 8], h[w, 9], h[w, 10], h[w, 13], h[w, 6]))
 
 
 if __name__ == "__main__":
