@@ -1,7 +1,7 @@
 #!/bin/bash
 # One GPU-box session: GPU test suite, the headline bench line, rocprofv3 kernel stats of the same
 # command.  Usage (from the repo root, through gpurun):  bash tools/gpu_session.sh <tag> [what...]
-#   what: tests bench prof pmc dist1  (default: tests bench prof)
+#   what: tests bench bench1 prof pmc benchq dist1  (default: tests bench prof)
 set -u
 TAG=${1:-s}; shift || true
 WHAT=${*:-tests bench prof}
@@ -32,6 +32,12 @@ if has pmc; then
     (cd /tmp && timeout 2400 rocprofv3 --pmc "$@" --output-format csv -d /tmp/pmc_$name -- python3 $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-kernel-pass > /dev/null 2> $GRAFT_REPO_ROOT/$OUT/pmc_$name.err); echo "pmc $name rc=$?"
   done
   python tools/pmc_summary.py $OUT/pmc_summary_bench_256clips.json /tmp/pmc_A /tmp/pmc_C /tmp/pmc_D && head -c 1500 $OUT/pmc_summary_bench_256clips.json
+fi
+if has benchq; then
+  # the headline line once more, now that the PMC summary of THESE kernel sources exists: roofline.traffic is quoted
+  mkdir -p profiles/$TAG && cp $OUT/pmc_summary_bench_256clips.json profiles/$TAG/pmc_summary_bench_256clips.json
+  timeout 1200 python bench.py --steps 3 --warmup 1 > $OUT/bench_256_with_traffic.json 2> $OUT/bench_256_with_traffic.err; echo "benchq rc=$?"
+  tail -c 1200 $OUT/bench_256_with_traffic.json
 fi
 if has dist1; then
   # the world > 1 branch of bench.py on the one GPU there is: 2 ranks share device 0, gloo all-gather
