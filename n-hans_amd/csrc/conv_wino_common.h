@@ -230,6 +230,8 @@ __device__ __forceinline__ void wino_epilogue(const ConvArgs& a, const f32x16 (*
     }
     const float osc = CONV_KARG(out_scale), slim = CONV_KARG(sat_limit);
     char* const outb = reinterpret_cast<char*>(a.out + fpix * a.ldo);
+    // (raw buffer over this frame's output: base and size are uniform; 0x00020000 = 32-bit data format, gfx9 family)
+    const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(outb, 0, a.Ho * a.Wo * a.ldo * 4, 0x00020000);
     int n_again = n;                                           // (recomputed, not kept: one register fewer across the transform)
     asm volatile("" : "+v"(n_again));
     const uint32_t oo0 = (uint32_t)pix0 * (uint32_t)a.ldo * 4u + (uint32_t)((n_again >> 5) * 64 + (n_again & 31)) * 2u, ost = (uint32_t)a.ldo * 4u;
@@ -269,11 +271,14 @@ __device__ __forceinline__ void wino_epilogue(const ConvArgs& a, const f32x16 (*
         split_pair(yc[2], yc[3], &hb.y, &lb.y);
         split_pair(yc[4], yc[5], &hb.z, &lb.z);
         split_pair(yc[6], yc[7], &hb.w, &lb.w);
-        if (valid && !(kDev && (a.wino_m >> 8 & 8))) {
-            char* dst = outb + (oo0 + (uint32_t)i * ost);
+        // The two stores of a column are UNCONDITIONAL buffer stores (an invalid column's offset lies beyond the frame: the
+        // range check of the descriptor drops it): behind an `if (valid)` the compiler's count of stores in flight is a
+        // guess, and the next column's table wait became "all earlier stores have completed".
+        {
             typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-            __builtin_nontemporal_store(u32x4{hb.x, hb.y, hb.z, hb.w}, reinterpret_cast<u32x4*>(dst));   // (written once, read by the next launch)
-            __builtin_nontemporal_store(u32x4{lb.x, lb.y, lb.z, lb.w}, reinterpret_cast<u32x4*>(dst + 64));
+            const uint32_t so = (valid && !(kDev && (a.wino_m >> 8 & 8))) ? oo0 + (uint32_t)i * ost : 0x80000000u;
+            __builtin_amdgcn_raw_buffer_store_b128(u32x4{hb.x, hb.y, hb.z, hb.w}, orsrc, so, 0, 2);          // (2 = nt: written once, read by the next launch)
+            __builtin_amdgcn_raw_buffer_store_b128(u32x4{lb.x, lb.y, lb.z, lb.w}, orsrc, so + 64u, 0, 2);
         }
         __builtin_amdgcn_sched_barrier(0);                     // (column by column: bounded register pressure)
     }

@@ -25,9 +25,6 @@ def main():
     defaults = {"epilogue_wide": 1, "consumer_interleave": 1}
     for kind in ("denoiser", "separator"):
         eng = engine.Engine(kind, precision="f16x3")
-        if not hip.ab_build(eng.handle):            # default build: the A/B kernels are not in the library
-            knobs = ("epilogue_wide", "consumer_interleave")
-            defaults = {"epilogue_wide": 1, "consumer_interleave": 1}
         variants = [-1, -1, 0, 1, 2]
         pool = []
         for i in range(14):
