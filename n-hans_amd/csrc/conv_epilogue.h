@@ -226,6 +226,10 @@ __device__ __forceinline__ void conv_epilogue_sweep8(const ConvArgs& a, const fl
     const int hoff = (n >> 5) * 64 + (n & 31);                // half index inside a split-NHWC pixel (n % 8 == 0)
     const float lo_clamp = a.relu ? 0.f : -3.0e38f;
     int sat = 0;
+    // raw buffer over the output from the tile's first pixel on (uniform; every valid pixel of the tile lies behind it)
+    const int mb = __builtin_amdgcn_readfirstlane(rowinfo[0].z);
+    const uint32_t ost = (uint32_t)a.ldo * 4u;
+    const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(a.out + (size_t)mb * a.ldo, 0, 0x7FFFFFFF, 0x00020000);
 
     auto issue = [&](int g, Epi8Raw<IDM> (&r)[GP]) {
 #pragma unroll
@@ -284,10 +288,15 @@ __device__ __forceinline__ void conv_epilogue_sweep8(const ConvArgs& a, const fl
             }
             sat |= (over && valid) ? 1 : 0;
             asm volatile("" : "+v"(sat));              // (here, not after the sweep: the values would stay alive for it)
-            if (valid) {
-                _Float16* dst = reinterpret_cast<_Float16*>(a.out + (size_t)r[u].m * a.ldo) + hoff;
-                __builtin_nontemporal_store(h, reinterpret_cast<f16x8*>(dst));                // (written once)
-                __builtin_nontemporal_store(l, reinterpret_cast<f16x8*>(dst + 32));
+            // The two stores are UNCONDITIONAL buffer stores relative to the tile's first pixel (a slot that is not
+            // stored gets an offset beyond the descriptor's 2 GB: the range check drops it).  Behind an `if (valid)` the
+            // compiler's count of what is in flight is a guess after the branch, and the waits for the NEXT group's loads
+            // (requested before this group's stores) came out as "all but the five youngest requests have completed".
+            {
+                typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+                const uint32_t so = valid ? (uint32_t)(r[u].m - mb) * ost + (uint32_t)hoff * 2u : 0x80000000u;
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, h), orsrc, so, 0, 2);       // (2 = nt: written once)
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, l), orsrc, so + 64u, 0, 2);
             }
         }
     };
