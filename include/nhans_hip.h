@@ -122,6 +122,9 @@ void nhans_destroy(nhans_ctx* ctx);
  *          "winograd" (1, default: in split-f16 mode the stride-1 4x4 convs of the residual stack run as 1-D
  *           Winograd convolutions F(5,4) along the image width, 2.5 x fewer matrix-core MACs -- conv_wino.hip;
  *           0: the direct kernels for every conv -- results agree to ~1e-5 on the logits),
+ *          "winograd_f32_tensors" (1, default: with the Winograd form, the stack tensors that only Winograd launches read
+ *           are stored f32 NHWC instead of split NHWC -- same size, same scaled values, less work in the transform;
+ *           0: every tensor split -- results agree to ~1e-6 on the logits),
  * (A `make DEV=1` build adds "debug_cycles_ptr" and the NHANS_ABLATE environment switch used by tools/; the default build has no developer hooks and reads no environment.)
  * Besides the workspace a context holds 64 MB of split-K scratch for the few launches that are
  * too small to fill the chip (the head's dense layer, the embedding tower at a few clips). */

@@ -146,7 +146,13 @@ __global__ void __launch_bounds__(256) direct_conv64_4x4(const DirectArgs a, int
                 __builtin_nontemporal_store(hi, reinterpret_cast<h4*>(line));
                 __builtin_nontemporal_store(lo, reinterpret_cast<h4*>(line + 32));
             } else {
-                *reinterpret_cast<float4*>(a.out + m * 64 + c) = acc;
+                // (f32 storage of a tensor the Winograd kernel reads, or the f32 mode: the same flag and clamp as a split
+                // store -- the reader's transform re-splits what it reads)
+                if (a.sat && split_clamp(acc, a.sat_limit)) atomicOr(a.sat, kSatActivation);
+                {
+                    typedef float fx4 __attribute__((ext_vector_type(4)));
+                    __builtin_nontemporal_store(fx4{acc.x, acc.y, acc.z, acc.w}, reinterpret_cast<fx4*>(a.out + m * 64 + c));
+                }
             }
         }
     }
@@ -167,6 +173,17 @@ void launch_unsplit(const float* src, int64_t M, int C, float scale, float* dst,
     int64_t blocks = (total + 255) / 256;
     if (blocks > 256 * 32) blocks = 256 * 32;
     NHANS_LAUNCH("unsplit", unsplit_kernel, dim3((unsigned)blocks), dim3(256), 0, s, src, total, C, scale, dst);
+}
+
+__global__ void __launch_bounds__(256) scale_copy_kernel(const float* src, size_t n, float scale, float* dst) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) dst[i] = src[i] * scale;
+}
+
+void launch_scale_copy(const float* src, size_t n, float scale, float* dst, hipStream_t s) {
+    if (n == 0) return;
+    size_t blocks = (n + 255) / 256;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    NHANS_LAUNCH("scale_copy", scale_copy_kernel, dim3((unsigned)blocks), dim3(256), 0, s, src, n, scale, dst);
 }
 
 // Calibration tap (nhans_api.hip: activation exponents): running maximum of |x| * scale over a tensor.  Split tensors

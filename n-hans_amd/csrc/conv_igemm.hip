@@ -340,6 +340,14 @@ double launch_conv_igemm(const ConvArgs& a0, hipStream_t s, const char** kernel,
     for (int i = 0; i < a.nseg; ++i) k += (double)a.seg[i].nchunks * BK;
     const char* name = "conv_igemm";
     const bool wide = a.N % 128 == 0;
+    // an f32-stored input in the split mode is something only conv_wino.hip reads: the caller (nhans_api.hip:
+    // stored_f32) decides both from the same predicate; a disagreement must not run a kernel on the wrong layout
+    if (a.prec == 1 && a.in_f32 && !(a.variant >= 2 && a.kgroup >= 0 && conv_wino_eligible(a))) {
+        note_launch("conv (f32-stored input without a Winograd form)", hipErrorInvalidValue);
+        if (kernel) *kernel = "refused";
+        if (mfma_flops) *mfma_flops = 0;
+        return 0;
+    }
     if (a.variant >= 1) {
         // (layers marked for grouped summation / split-K always take the LDS-DMA kernel, whatever the
         // launch size: the choice must not depend on the batch)

@@ -60,7 +60,10 @@ constexpr size_t kWinoLds = kWinoLdsEpi > kWinoLdsLoop ? kWinoLdsEpi : kWinoLdsL
 static_assert(kWinoLds <= 160 * 1024, "LDS of a gfx950 CU");
 }  // namespace
 
-template <int KH, int MO, int DBG = 0>      // DBG: dev tool, per-wave cycle stamps (tools/wino_phase_cycles.py)
+// DBG: dev tool, per-wave cycle stamps (tools/wino_phase_cycles.py).  INF: the input tensor is f32 NHWC instead of split
+// NHWC (a tensor that only Winograd launches read is stored so: the transform then has no hi + lo to add up -- 64 of its
+// ~ 215 instructions per chunk -- and reads its eight pixels as 16-byte pieces; the producing epilogue skips the split).
+template <int KH, int MO, int DBG = 0, int INF = 0>
 __global__ void __launch_bounds__(XW * 64) conv_wino(const ConvArgs a) {
     static_assert(KH == 4, "a k-step pairs two filter rows");
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -102,7 +105,8 @@ __global__ void __launch_bounds__(XW * 64) conv_wino(const ConvArgs a) {
         const int hrow = r0 + row - g.pt, wcol = j0 * MO - g.pl + px;
         const bool ok = kind < 2 && row < nrows && px < TJ * MO + KH - 1 && (unsigned)hrow < (unsigned)g.H && (unsigned)wcol < (unsigned)g.W;
         // split NHWC: a 32-channel group of a pixel is 64 B of hi halfs followed by 64 B of lo halfs
-        goff[k] = ok ? (unsigned)(((hrow * g.W + wcol) * C) * 4 + kind * 64) : 0xFFFFFFFFu;
+        // (f32 NHWC: the chunk's 8 channels are 32 contiguous bytes, kind = their first | second 16)
+        goff[k] = ok ? (unsigned)(((hrow * g.W + wcol) * C) * 4 + kind * (INF ? 16 : 64)) : 0xFFFFFFFFu;
     }
     const bool last_real = wave + XW * (X_DPW - 1) < X_NDMA;     // (uniform) the wave's last slot carries pieces
     // tile of chunk CC -> staged buffer RB (a chunk past the end: nothing, into the dump area)
@@ -110,7 +114,7 @@ __global__ void __launch_bounds__(XW * 64) conv_wino(const ConvArgs a) {
     {                                                                                              \
         const int cc_ = (CC);                                                                      \
         const bool live_ = cc_ < NC && !(kDev && (a.wino_m >> 8 & 1) && cc_ > 0);                  \
-        const unsigned co_ = (unsigned)((cc_ >> 2) * 128 + (cc_ & 3) * 16);                        \
+        const unsigned co_ = INF ? (unsigned)(cc_ * 32) : (unsigned)((cc_ >> 2) * 128 + (cc_ & 3) * 16); \
         float* const dst_ = smem + X_RAW_BASE + (RB) * X_RAW + wave * 256;                         \
         _Pragma("unroll") for (int k = (K0); k < (K0) + 2; ++k) {                                  \
             const char* s_ = (goff[k] != 0xFFFFFFFFu && live_) ? fbp + (goff[k] + co_) : zp;       \
@@ -130,7 +134,8 @@ __global__ void __launch_bounds__(XW * 64) conv_wino(const ConvArgs a) {
     const int t_slot = t_active ? task >> 1 : 0, t_half = task & 1;
     const int t_rs = t_slot / TJ, t_tj = t_slot - t_rs * TJ;
     // LDS byte addresses (dynamic LDS starts at 0: the kernel has no static LDS)
-    const unsigned t_src = (unsigned)((X_RAW_BASE + (t_rs * X_RPX + t_tj * MO) * 4 + t_half * 2) * 4);   // + RB*X_RAW*4 (+ X_RKIND*4: lo)
+    const unsigned t_src = INF ? (unsigned)((X_RAW_BASE + t_half * X_RKIND + (t_rs * X_RPX + t_tj * MO) * 4) * 4)   // f32: the task's 4 channels are one piece kind
+                               : (unsigned)((X_RAW_BASE + (t_rs * X_RPX + t_tj * MO) * 4 + t_half * 2) * 4);   // + RB*X_RAW*4 (+ X_RKIND*4: lo)
     const unsigned t_dst = (unsigned)((t_slot * 4 + t_half * 2) * 4);                                       // + VB*X_VBUF*4 + (p*2 + h)*X_PLANE*4
     // BT, structured (fold.py: WINO_BT): even and odd parts of rows 1..6 share their sums.  ONE channel at a time, in
     // scalar f32 instructions on purpose: beside a running MFMA stream a packed-f32 instruction (v_pk_fma_f32,
@@ -175,8 +180,17 @@ __global__ void __launch_bounds__(XW * 64) conv_wino(const ConvArgs a) {
         const unsigned rs_ = t_src + (unsigned)((RB) * X_RAW * 4);                                 \
         const unsigned vd_ = t_dst + (unsigned)((VB) * X_VBUF * 4);                                \
         f32x2 rh_[8], rl_[8];                                                                      \
+        f32x4 rf_[8];                                                                              \
         /* (every lane runs the arithmetic -- idle lanes on slot 0 --, only the stores are predicated: no control flow \
            between the requests) */                                                                \
+        if constexpr (INF) {                                                                       \
+            asm volatile(                                                                          \
+                "ds_read_b128 %0, %8\n ds_read_b128 %1, %8 offset:16\n ds_read_b128 %2, %8 offset:32\n ds_read_b128 %3, %8 offset:48\n" \
+                "ds_read_b128 %4, %8 offset:64\n ds_read_b128 %5, %8 offset:80\n ds_read_b128 %6, %8 offset:96\n ds_read_b128 %7, %8 offset:112\n" \
+                "s_waitcnt lgkmcnt(0)"                                                             \
+                : "=&v"(rf_[0]), "=&v"(rf_[1]), "=&v"(rf_[2]), "=&v"(rf_[3]), "=&v"(rf_[4]), "=&v"(rf_[5]), "=&v"(rf_[6]), "=&v"(rf_[7]) \
+                : "v"(rs_) : "memory");                                                            \
+        } else {                                                                                   \
             asm volatile(                                                                          \
                 "ds_read_b64 %0, %16\n ds_read_b64 %1, %16 offset:16\n ds_read_b64 %2, %16 offset:32\n ds_read_b64 %3, %16 offset:48\n" \
                 "ds_read_b64 %4, %16 offset:64\n ds_read_b64 %5, %16 offset:80\n ds_read_b64 %6, %16 offset:96\n ds_read_b64 %7, %16 offset:112\n" \
@@ -186,15 +200,21 @@ __global__ void __launch_bounds__(XW * 64) conv_wino(const ConvArgs a) {
                 : "=&v"(rh_[0]), "=&v"(rh_[1]), "=&v"(rh_[2]), "=&v"(rh_[3]), "=&v"(rh_[4]), "=&v"(rh_[5]), "=&v"(rh_[6]), "=&v"(rh_[7]), \
                   "=&v"(rl_[0]), "=&v"(rl_[1]), "=&v"(rl_[2]), "=&v"(rl_[3]), "=&v"(rl_[4]), "=&v"(rl_[5]), "=&v"(rl_[6]), "=&v"(rl_[7]) \
                 : "v"(rs_), "n"(X_RKIND * 4) : "memory");                                          \
+        }                                                                                          \
         X_TSTAMP(0)                                                                                \
         if ((REQ) == 2) X_LOAD_B2(0, 0, u_)                                                        \
         uint2 oh_[8], ol_[8];                                                                      \
         _Pragma("unroll") for (int ep = 0; ep < 2; ++ep) {                                         \
             float d0_[8], d1_[8], v0_[8], v1_[8];                                                  \
             _Pragma("unroll") for (int x = 0; x < 8; ++x) {                                        \
-                const float hp_ = rh_[x][ep], lp_ = rl_[x][ep];                                    \
-                d0_[x] = unsplit_mix<0>(hp_, lp_);                                                 \
-                d1_[x] = unsplit_mix<1>(hp_, lp_);                                                 \
+                if constexpr (INF) {                                                               \
+                    d0_[x] = rf_[x][2 * ep];                                                       \
+                    d1_[x] = rf_[x][2 * ep + 1];                                                   \
+                } else {                                                                           \
+                    const float hp_ = rh_[x][ep], lp_ = rl_[x][ep];                                \
+                    d0_[x] = unsplit_mix<0>(hp_, lp_);                                             \
+                    d1_[x] = unsplit_mix<1>(hp_, lp_);                                             \
+                }                                                                                  \
             }                                                                                      \
             __builtin_amdgcn_sched_barrier(0);                                                     \
             if (ep == 0) { if ((REQ) == 2) X_LOAD_B2(0, 1, u_) } else if (REQ) { X_DMA2(DC, DB, 0) }  \
@@ -456,12 +476,12 @@ void wino_block(int Ho, int ntile, int KH, int m, int* tr, int* tj) {
         }
 }
 
-template <int KH, int MO, int DBG = 0> void launch_wino_t(const ConvArgs& a, hipStream_t s) {
+template <int KH, int MO, int DBG = 0, int INF = 0> void launch_wino_t(const ConvArgs& a, hipStream_t s) {
     static unsigned long long attr_devices = 0;
-    set_max_dynamic_lds(reinterpret_cast<const void*>(&conv_wino<KH, MO, DBG>), kWinoLds, &attr_devices, "conv_wino");
+    set_max_dynamic_lds(reinterpret_cast<const void*>(&conv_wino<KH, MO, DBG, INF>), kWinoLds, &attr_devices, "conv_wino");
     const int frames = a.M / (a.Ho * a.Wo);
     const int grid = frames * a.wino_nrb * a.wino_ncb * (a.N / 64);
-    NHANS_LAUNCH("conv_wino", (conv_wino<KH, MO, DBG>), dim3(grid), dim3(XW * 64), kWinoLds, s, a);
+    NHANS_LAUNCH("conv_wino", (conv_wino<KH, MO, DBG, INF>), dim3(grid), dim3(XW * 64), kWinoLds, s, a);
 }
 
 void wino_geometry(ConvArgs& a) {
@@ -481,7 +501,7 @@ bool conv_wino_eligible(const ConvArgs& a) {
     const ConvSeg& g = a.seg[0];
     if (!a.wino || !a.wino_u || !a.wino_ws || a.prec != 1 || a.nseg != 1 || a.kgroup != 0) return false;
     if (g.KH != 4 || g.KW != g.KH || g.sh != 1 || g.sw != 1 || a.Wo != g.W || a.Ho != g.H) return false;   // (3x3: F(6,3) not built)
-    if (g.C % 16 != 0 || a.N % 64 != 0 || a.Nreal != a.N || !a.out_split || a.aux) return false;
+    if (g.C % 16 != 0 || a.N % 64 != 0 || a.Nreal != a.N || a.aux) return false;            // (out: split or f32 NHWC)
     if (a.id_mode == 1 && !a.id_split && (a.id_ld & 3)) return false;
     if (a.M % (a.Ho * a.Wo) != 0) return false;
     if (a.tf && (!a.tt || !a.ff)) return false;                        // the epilogue reads the table's two terms
@@ -505,9 +525,18 @@ void launch_conv_wino(const ConvArgs& a0, hipStream_t s) {
 #ifdef NHANS_DEV
     // NHANS_ABLATE (timing experiments, wrong results): 1 input tiles of chunks >= 1 from the zero page, 2 no MFMAs,
     // 4 no transforms after the first chunk, 8 residual from one L2-hot line and no stores
-    if (a.dbg) { a.wino_m |= (dev_ablate() & 31) << 8; launch_wino_t<4, 5, 1>(a, s); return; }
+    if (a.dbg) {
+        a.wino_m |= (dev_ablate() & 31) << 8;
+        if (a.in_f32) launch_wino_t<4, 5, 1, 1>(a, s); else launch_wino_t<4, 5, 1>(a, s);
+        return;
+    }
 #endif
-    launch_wino_t<4, 5>(a, s);
+#ifdef NHANS_WINO_F32IN_TIMING
+    launch_wino_t<4, 5, 0, 1>(a, s);       // (timing experiment, wrong results: every input read as if it were f32)
+    return;
+#endif
+    if (a.in_f32) launch_wino_t<4, 5, 0, 1>(a, s);
+    else launch_wino_t<4, 5>(a, s);
 }
 
 }  // namespace nhans

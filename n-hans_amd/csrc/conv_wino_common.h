@@ -235,6 +235,8 @@ __device__ __forceinline__ void wino_epilogue(const ConvArgs& a, const f32x16 (*
     int n_again = n;                                           // (recomputed, not kept: one register fewer across the transform)
     asm volatile("" : "+v"(n_again));
     const uint32_t oo0 = (uint32_t)pix0 * (uint32_t)a.ldo * 4u + (uint32_t)((n_again >> 5) * 64 + (n_again & 31)) * 2u, ost = (uint32_t)a.ldo * 4u;
+    const uint32_t oo0f = (uint32_t)pix0 * (uint32_t)a.ldo * 4u + (uint32_t)n_again * 4u;
+    const bool osplit = a.out_split != 0;
     int sat = 0;
 #pragma unroll
     for (int i = 0; i < MO; ++i) {
@@ -274,11 +276,19 @@ __device__ __forceinline__ void wino_epilogue(const ConvArgs& a, const f32x16 (*
         // The two stores of a column are UNCONDITIONAL buffer stores (an invalid column's offset lies beyond the frame: the
         // range check of the descriptor drops it): behind an `if (valid)` the compiler's count of stores in flight is a
         // guess, and the next column's table wait became "all earlier stores have completed".
+        // Output layout: split NHWC (16 bytes of hi halves, 16 of lo halves, 64 apart) or, for a tensor that only
+        // Winograd launches read, f32 NHWC (the 8 channels' 32 contiguous bytes; the same scaled, clamped values) --
+        // chosen by selects, not by a branch, for the same reason.
         {
             typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-            const uint32_t so = (valid && !(kDev && (a.wino_m >> 8 & 8))) ? oo0 + (uint32_t)i * ost : 0x80000000u;
-            __builtin_amdgcn_raw_buffer_store_b128(u32x4{hb.x, hb.y, hb.z, hb.w}, orsrc, so, 0, 2);          // (2 = nt: written once, read by the next launch)
-            __builtin_amdgcn_raw_buffer_store_b128(u32x4{lb.x, lb.y, lb.z, lb.w}, orsrc, so + 64u, 0, 2);
+            const bool ok = valid && !(kDev && (a.wino_m >> 8 & 8));
+            const uint32_t so = ok ? (osplit ? oo0 : oo0f) + (uint32_t)i * ost : 0x80000000u;
+            const u32x4 d0 = osplit ? u32x4{hb.x, hb.y, hb.z, hb.w}
+                                    : u32x4{__builtin_bit_cast(unsigned, yc[0]), __builtin_bit_cast(unsigned, yc[1]), __builtin_bit_cast(unsigned, yc[2]), __builtin_bit_cast(unsigned, yc[3])};
+            const u32x4 d1 = osplit ? u32x4{lb.x, lb.y, lb.z, lb.w}
+                                    : u32x4{__builtin_bit_cast(unsigned, yc[4]), __builtin_bit_cast(unsigned, yc[5]), __builtin_bit_cast(unsigned, yc[6]), __builtin_bit_cast(unsigned, yc[7])};
+            __builtin_amdgcn_raw_buffer_store_b128(d0, orsrc, so, 0, 2);          // (2 = nt: written once, read by the next launch)
+            __builtin_amdgcn_raw_buffer_store_b128(d1, orsrc, so + (osplit ? 64u : 16u), 0, 2);
         }
         __builtin_amdgcn_sched_barrier(0);                     // (column by column: bounded register pressure)
     }

@@ -135,6 +135,7 @@ struct nhans_ctx {
     int epi8 = 1;               // ConvArgs::epi8
     int ilv = 1;                // ConvArgs::ilv
     int wino = 1;               // ConvArgs::wino: 1-D Winograd form of the stride-1 stack convs (conv_wino.hip)
+    int wino_f32 = 1;           // tensors that only Winograd launches read are stored f32 NHWC (stored_f32())
     long long* dbg = nullptr;   // NHANS_DEV builds: per-workgroup cycle stamps of the last conv launch
     int* status_dev = nullptr;  // sticky NHANS_STATUS_* bits set by kernels (nhans_take_status)
     // Activation exponents: a split-f16 tensor is stored as x * 2^-e with one e per tensor of the network, chosen from
@@ -291,14 +292,29 @@ void run_conv(nhans_ctx* c, const ConvArgs& a0, hipStream_t s) {
 // launch that writes its input raises the saturation flag at kSatLimitWinoInput.
 bool wino_reader(const nhans_ctx* c, int b, int cv) {
     if (b < 0 || b > 7 || !c->wino || c->prec != 1 || (c->conv_variant >= 0 && c->conv_variant < 2)) return false;
-    const std::string n = "m" + std::to_string(b) + ".c" + std::to_string(cv) + ".wino";
+    const std::string l = "m" + std::to_string(b) + ".c" + std::to_string(cv), n = l + ".wino";
+    // (conv_wino_eligible: the kernel's epilogue reads the position table as its two terms only)
+    if (c->A(l + ".tf") && !(c->A(l + ".tt") && c->A(l + ".ff"))) return false;
     return c->A(n) && c->A(n + ".ws");
 }
 float sat_limit_for(const nhans_ctx* c, int b, int cv) { return wino_reader(c, b, cv) ? kSatLimitWinoInput : kSatLimitF16; }
 
+// Is stack tensor (block b; cv 0: conv1's output, 1: the block's output) stored as f32 NHWC in the split-f16 mode?  Yes if
+// every launch that reads it is a Winograd launch -- conv_wino.hip reads either layout (its transform works in f32 and
+// re-splits: with an f32 input it has no hi + lo to add up, 64 of its ~215 instructions per chunk), the direct kernels
+// stage split pieces straight into MFMA operands -- and the launch that writes it is direct_conv64 or a Winograd launch.
+// The values are the same scaled, clamped ones a split store would hold to 22 bits; 4 bytes per element either way.
+bool stored_f32(const nhans_ctx* c, int b, int cv) {
+    if (c->prec != 1 || !c->wino_f32 || b < 0 || b > 7) return false;
+    if (cv == 0) return wino_reader(c, b, 2) && (b == 0 || wino_reader(c, b, 1));
+    if (b == 7) return false;
+    const BlockGeo& nx = c->stack[b + 1];             // read by conv1 of the next block and, in an identity block, by its conv2's epilogue
+    return wino_reader(c, b, 2) && wino_reader(c, b + 1, 1) && nx.cin == nx.cout && wino_reader(c, b + 1, 2);
+}
+
 // Calibration tap: the running |x| maximum of tensor `idx` (`words` values, stored in the active precision's layout).
-void tap(nhans_ctx* c, int idx, const float* buf, size_t words, hipStream_t s) {
-    if (c->calibrating) launch_absmax(buf, words, c->prec, c->up(idx), c->amax_dev + idx, s);
+void tap(nhans_ctx* c, int idx, const float* buf, size_t words, hipStream_t s, bool f32_layout = false) {
+    if (c->calibrating) launch_absmax(buf, words, c->prec && !f32_layout, c->up(idx), c->amax_dev + idx, s);
 }
 
 // ---- embedding tower for `n` context images already in HBM ----------------------------------
@@ -320,7 +336,7 @@ int embed_impl(nhans_ctx* c, const float* ctx_lm, int n, float* emb_out, float* 
                 d.Ho = g.hout; d.Wo = g.wout; d.M = nc * g.hout * g.wout; d.out = a1;
                 d.cb = c->A(p + ".c1.cb"); d.cb_stride = 0; d.img_clip = nullptr; d.tf = nullptr; d.tt = nullptr; d.ff = nullptr;
                 d.relu = 1; d.fdHoWo = make_fastdiv(g.hout * g.wout); d.fdWo = make_fastdiv(g.wout);
-                d.out_split = c->prec; d.sat = c->status_dev; d.out_scale = c->down(TA(0, 0)); d.sat_limit = kSatLimitF16;
+                d.out_split = c->prec; d.sat = c->prec ? c->status_dev : nullptr; d.out_scale = c->down(TA(0, 0)); d.sat_limit = kSatLimitF16;
                 Prof pr(c, s, "direct_conv64");
                 launch_direct_conv64(d, s);
                 pr.done(2.0 * d.M * g.kh * g.kw * 64, 0);
@@ -434,7 +450,7 @@ float* run_stack_chunk(nhans_ctx* c, const float* logmag, const StackBufs& sb, i
             d.cb = cb1; d.cb_stride = c->cond_cols; d.img_clip = clipmap;
             d.tf = c->A(p + ".c1.tf"); d.tt = c->A(p + ".c1.tt"); d.ff = c->A(p + ".c1.ff");
             if (!d.tt || !d.ff) d.tt = d.ff = nullptr;
-            d.relu = 1; d.out_split = c->prec; d.sat = c->status_dev;
+            d.relu = 1; d.out_split = c->prec && !stored_f32(c, 0, 0); d.sat = c->prec ? c->status_dev : nullptr;
             d.out_scale = c->down(SA(0, 0)); d.sat_limit = sat_limit_for(c, 0, 2);
             d.fdHoWo = make_fastdiv(g.hout * g.wout); d.fdWo = make_fastdiv(g.wout);
             Prof pr(c, s, "direct_conv64");
@@ -452,9 +468,10 @@ float* run_stack_chunk(nhans_ctx* c, const float* logmag, const StackBufs& sb, i
             a.wino_u = c->A(p + ".c1.wino"); a.wino_ws = c->A(p + ".c1.wino.ws");
             a.in_scale = c->up(SA(b - 1, 1)); a.out_scale = c->down(SA(b, 0));
             a.sat_limit = sat_limit_for(c, b, 2);
+            a.in_f32 = stored_f32(c, b - 1, 1); a.out_split = c->prec && !stored_f32(c, b, 0);
             run_conv(c, a, s);
         }
-        tap(c, SA(b, 0), a1, (size_t)n * g.hout * g.wout * g.cout, s);
+        tap(c, SA(b, 0), a1, (size_t)n * g.hout * g.wout * g.cout, s, stored_f32(c, b, 0));
         ConvArgs a{};
         fill_epilogue_defaults(c, a);
         a.nseg = 1;
@@ -466,14 +483,16 @@ float* run_stack_chunk(nhans_ctx* c, const float* logmag, const StackBufs& sb, i
         a.wino_u = c->A(p + ".c2.wino"); a.wino_ws = c->A(p + ".c2.wino.ws");
         a.in_scale = c->up(SA(b, 0)); a.out_scale = c->down(SA(b, 1));
         a.sat_limit = sat_limit_for(c, b + 1, 1);
+        a.in_f32 = stored_f32(c, b, 0); a.out_split = c->prec && !stored_f32(c, b, 1);
         float* out;
         if (b == 0) {                       // 1 -> 64 transform on the window image itself
             a.id_mode = 2; a.id = sb.xw; a.idH = g.hin; a.idW = g.win; a.idsh = 1; a.idsw = 1;
             out = x;
         } else if (g.cin == g.cout) {       // identity shortcut, written in place over the block input
-            a.id_mode = 1; a.id = x; a.id_ld = g.cout; a.id_split = c->prec;
+            a.id_mode = 1; a.id = x; a.id_ld = g.cout; a.id_split = c->prec && !stored_f32(c, b - 1, 1);
             a.id_scale = c->up(SA(b - 1, 1));
-            out = x;
+            // (in place only if input and output share a layout: a thread's output bytes are its residual bytes then)
+            out = stored_f32(c, b - 1, 1) == stored_f32(c, b, 1) ? x : y;
         } else if (c->wino && c->prec == 1 && g.kh == 4 && a.variant >= 2 && a.wino_u && a.wino_ws) {
             // Channel-changing block whose conv2 has a Winograd form: the 1x1 strided `_transform` conv cannot ride in
             // the K loop of the transformed domain, so it runs first on its own (3 % of the block's MACs) into an f32
@@ -498,7 +517,7 @@ float* run_stack_chunk(nhans_ctx* c, const float* logmag, const StackBufs& sb, i
         }
         set_out_geometry(a, n, g.hout, g.wout, g.cout, g.cout, g.cout, out);
         run_conv(c, a, s);
-        tap(c, SA(b, 1), out, (size_t)n * g.hout * g.wout * g.cout, s);
+        tap(c, SA(b, 1), out, (size_t)n * g.hout * g.wout * g.cout, s, stored_f32(c, b, 1));
         if (out == y) std::swap(x, y);
     }
     if (upto >= 9) {                        // last_conv [5,1] VALID + BN + ReLU  (SN/main.py:232-236)
@@ -934,6 +953,7 @@ int nhans_set_option(nhans_ctx* c, const char* key, int64_t value) {
         }
     }
     else if (k == "winograd") c->wino = value != 0;
+    else if (k == "winograd_f32_tensors") c->wino_f32 = value != 0;
     else if (k == "precision") {
         if (value != 0 && value != 1) return fail(NHANS_EINVAL, "precision must be 0 (f32) or 1 (f16x3)");
         if (value == 1 && !c->A("head.dense.wpk_h"))
@@ -1049,7 +1069,8 @@ static int debug_block_output_body(nhans_ctx* c, const float* logmag, const int6
     size_t per;
     if (block == 8) per = (size_t)26 * 512;
     else per = (size_t)c->stack[block].hout * c->stack[block].wout * c->stack[block].cout;
-    if (c->prec) launch_unsplit(res, (int64_t)nframes * (int64_t)(per / (block == 8 ? 512 : c->stack[block].cout)),
+    if (c->prec && block < 8 && stored_f32(c, block, 1)) launch_scale_copy(res, per * nframes, c->up(SA(block, 1)), out, s);
+    else if (c->prec) launch_unsplit(res, (int64_t)nframes * (int64_t)(per / (block == 8 ? 512 : c->stack[block].cout)),
                                 block == 8 ? 512 : c->stack[block].cout, c->up(block == 8 ? kActHead : SA(block, 1)), out, s);
     else HIP_TRY(hipMemcpyAsync(out, res, per * nframes * 4, hipMemcpyDeviceToDevice, s));
     return NHANS_OK;

@@ -120,6 +120,8 @@ struct ConvArgs {
     int prec;              // 0: f32 MFMA on f32 NHWC; 1: split-f16 x3 MFMA on split NHWC inputs
     int out_split;         // write `out` as split NHWC (ldo = N words per pixel) instead of f32
     int id_split;          // id_mode 1 tensor is split NHWC
+    int in_f32;            // prec 1 only: seg[0].src is f32 NHWC (scaled like a split tensor) -- a tensor that only Winograd
+                           // launches read (conv_wino.hip, the one kernel that takes it)
     const float* ws;       // prec 1: per-channel power-of-two that undoes the weight pre-scaling
     // Split-f16 tensors are STORED times a per-tensor power of two 2^-e (nhans_api.hip: activation exponents), so that
     // what a trained or an odd model produces stays inside the f16 range.  The epilogue computes in the unscaled
@@ -195,6 +197,7 @@ struct DirectArgs {     // convolution of a 1-channel image into 64 channels, sa
 void launch_direct_conv64(const DirectArgs& a, hipStream_t s);
 // split NHWC [M, C] -> f32 [M, C], times `scale`
 void launch_unsplit(const float* src, int64_t M, int C, float scale, float* dst, hipStream_t s);
+void launch_scale_copy(const float* src, size_t n, float scale, float* dst, hipStream_t s);   // dst = src * scale (an f32-stored tensor out of its exponent)
 // *slot = max(*slot, scale * max|x|) over a tensor of `nwords` 32-bit words (f32 values, or pairs of f16 halfs of a
 // split-NHWC tensor: the hi halfs dominate); *slot holds the bits of a non-negative float.  Calibration only.
 void launch_absmax(const float* x, size_t nwords, int split, float scale, unsigned* slot, hipStream_t s);

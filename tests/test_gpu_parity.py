@@ -423,3 +423,33 @@ def test_winograd_convs_against_golden_logits(_eng_d, case, n):
     assert np.abs(got - g["logits"]).max() < LOGIT_TOL
     assert np.array_equal(lg, again)                    # bitwise reproducible
     assert _eng_d.take_status() == 0
+
+
+def test_f32_stored_winograd_tensors(_eng_d):
+    """Option winograd_f32_tensors (default 1): the five stack tensors that only Winograd launches read -- conv1's output
+    of resblock1_1 / 1_2 / 2_2 and the block outputs of resblock1_1 / 2_1 -- are stored f32 NHWC instead of split NHWC
+    (nhans_api.hip: stored_f32); 0 = every tensor split.  Same golden logits at the same bar either way, the block
+    outputs of the debug entry point (which has to know each tensor's layout) agree between the two to the split
+    format's 22 bits, and a layer whose input is f32-stored refuses to run in any other kernel."""
+    _eng_d.set_precision("f16x3")
+    g = load_case("case_exp2")
+    lm = torch.from_numpy(g["logmag"]).cuda()
+    ea = torch.from_numpy(g["emb_a"][None]).cuda()
+    eb = torch.from_numpy(g["emb_b"][None]).cuda()
+    out = {}
+    try:
+        for v in (0, 1):
+            _eng_d.set_option("winograd_f32_tensors", v)
+            lg = _eng_d.mask_net(lm, [0, 308], ea, eb)[0].cpu().numpy()
+            blocks = [_eng_d.block_output(lm, [0, 308], ea, eb, 100, 2, b).cpu().numpy() for b in range(4)]
+            assert _eng_d.take_status() == 0
+            out[v] = (lg, blocks)
+    finally:
+        _eng_d.set_option("winograd_f32_tensors", 1)
+    for v in (0, 1):
+        assert np.abs(out[v][0] - g["logits"]).max() < LOGIT_TOL
+    print("f32-stored vs split: logits %.3e" % np.abs(out[0][0] - out[1][0]).max())
+    assert np.abs(out[0][0] - out[1][0]).max() < 2e-5
+    for b in range(4):
+        a0, a1 = out[0][1][b], out[1][1][b]
+        assert a0.shape == a1.shape and np.abs(a0 - a1).max() <= 4e-6 * max(1.0, np.abs(a0).max()), b
