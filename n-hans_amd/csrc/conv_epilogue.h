@@ -62,6 +62,33 @@ __device__ __forceinline__ f32x4 epi_combine(f32x4 acc, f32x4 ws, f32x4 cb, f32x
     return fma4(idw, res, fma4(acc, ws, cb) + tf);
 }
 
+// split of two f32 values into packed f16 pairs: hi = RNE(v) (one v_cvt_pk_f16_f32), lo = RNE(v - hi) as one
+// v_fma_mixlo_f16 / v_fma_mixhi_f16 each (f16 source, f32 addend, f16 result into one half of the destination)
+__device__ __forceinline__ void split_pair(float vx, float vy, unsigned* hi, unsigned* lo) {
+    typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
+    const h2_t h = {(_Float16)vx, (_Float16)vy};
+    const unsigned hb = __builtin_bit_cast(unsigned, h);
+    unsigned l;
+    asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(l) : "v"(hb), "v"(vx));
+    asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(l) : "v"(hb), "v"(vy));
+    *hi = hb;
+    *lo = l;
+}
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ f16x8 as_h8(f32x4 v) { return __builtin_bit_cast(f16x8, v); }
+
+// value of a split-f16 element: (float)hi.half[SEL] + (float)lo.half[SEL] in ONE instruction (v_fma_mix_f32 reads
+// f16 halves of 32-bit registers as sources of an f32 fma; the compiler spends two conversions and an add on it)
+template <int SEL> __device__ __forceinline__ float unsplit_mix(float hi_pair, float lo_pair) {
+    float d;
+    if constexpr (SEL == 0) asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,1]" : "=v"(d) : "v"(hi_pair), "v"(lo_pair));
+    else asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[1,0,1] op_sel_hi:[1,0,1]" : "=v"(d) : "v"(hi_pair), "v"(lo_pair));
+    return d;
+}
+
 __device__ __forceinline__ float split_load(const float* base, size_t row_floats, int n) {
     // value (hi + lo) of channel n of a split-NHWC pixel whose line starts at base + row_floats
     const _Float16* p = reinterpret_cast<const _Float16*>(base + row_floats) + (n >> 5) * 64 + (n & 31);
@@ -261,9 +288,10 @@ __device__ __forceinline__ void conv_epilogue_sweep8(const ConvArgs& a, const fl
             const f32x4 av1 = *reinterpret_cast<const f32x4*>(ct + r[u].p * LDC + c8 * 8 + 4);
             f32x4 i0 = {0.f, 0.f, 0.f, 0.f}, i1 = i0;
             if constexpr (IDM == 1) {
-                const f16x8 h = r[u].h, l = r[u].l;
-                i0 = f32x4{(float)h[0] + (float)l[0], (float)h[1] + (float)l[1], (float)h[2] + (float)l[2], (float)h[3] + (float)l[3]};
-                i1 = f32x4{(float)h[4] + (float)l[4], (float)h[5] + (float)l[5], (float)h[6] + (float)l[6], (float)h[7] + (float)l[7]};
+                // (float)hi + (float)lo, one v_fma_mix_f32 per value (the same bits as two conversions and an add)
+                const f32x4 hv = __builtin_bit_cast(f32x4, r[u].h), lv = __builtin_bit_cast(f32x4, r[u].l);
+                i0 = f32x4{unsplit_mix<0>(hv.x, lv.x), unsplit_mix<1>(hv.x, lv.x), unsplit_mix<0>(hv.y, lv.y), unsplit_mix<1>(hv.y, lv.y)};
+                i1 = f32x4{unsplit_mix<0>(hv.z, lv.z), unsplit_mix<1>(hv.z, lv.z), unsplit_mix<0>(hv.w, lv.w), unsplit_mix<1>(hv.w, lv.w)};
             } else if constexpr (IDM == 3) {
                 i0 = f32x4{r[u].sv, r[u].sv, r[u].sv, r[u].sv};
                 i1 = i0;
@@ -276,16 +304,21 @@ __device__ __forceinline__ void conv_epilogue_sweep8(const ConvArgs& a, const fl
             // are used only there -- the restrict position table, the bias -- into the branch, right in front of
             // their use, and the software pipeline of issue() / finish() collapses into load, wait, store.
             const bool valid = r[u].m >= 0;
-            f16x8 h, l;
+            float yc[8];
             bool over = false;
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 const float y = fmaxf(e < 4 ? r0[e] : r1[e - 4], lo_clamp) * osc;
                 over |= !(fabsf(y) < slim);
-                const float yc = fminf(fmaxf(y, -65504.f), 65504.f);
-                h[e] = (_Float16)yc;
-                l[e] = (_Float16)(yc - (float)h[e]);
+                yc[e] = fminf(fmaxf(y, -65504.f), 65504.f);
             }
+            // hi = f16(y), lo = f16(y - hi): one packed conversion and two v_fma_mix per pair (the same bits as
+            // four conversions and a subtraction per value)
+            uint4 hq, lq;
+            split_pair(yc[0], yc[1], &hq.x, &lq.x);
+            split_pair(yc[2], yc[3], &hq.y, &lq.y);
+            split_pair(yc[4], yc[5], &hq.z, &lq.z);
+            split_pair(yc[6], yc[7], &hq.w, &lq.w);
             sat |= (over && valid) ? 1 : 0;
             asm volatile("" : "+v"(sat));              // (here, not after the sweep: the values would stay alive for it)
             // The two stores are UNCONDITIONAL buffer stores relative to the tile's first pixel (a slot that is not
@@ -295,8 +328,8 @@ __device__ __forceinline__ void conv_epilogue_sweep8(const ConvArgs& a, const fl
             {
                 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
                 const uint32_t so = valid ? (uint32_t)(r[u].m - mb) * ost + (uint32_t)hoff * 2u : 0x80000000u;
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, h), orsrc, so, 0, 2);       // (2 = nt: written once)
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, l), orsrc, so + 64u, 0, 2);
+                __builtin_amdgcn_raw_buffer_store_b128(u32x4{hq.x, hq.y, hq.z, hq.w}, orsrc, so, 0, 2);     // (2 = nt: written once)
+                __builtin_amdgcn_raw_buffer_store_b128(u32x4{lq.x, lq.y, lq.z, lq.w}, orsrc, so + 64u, 0, 2);
             }
         }
     };

@@ -14,32 +14,6 @@ constexpr int W_LDM = 68;                      // epilogue: floats per tile-pixe
 // LDS of one epilogue pass: eight M_p tiles of 64 tile-pixels + the block's constants (ws, idw, one bias row per block row)
 constexpr size_t kWinoLdsEpi = (size_t)(8 * 64 * W_LDM + (2 + 64) * 64) * sizeof(float);
 
-// split of two f32 values into packed f16 pairs: hi = RNE(v) (one v_cvt_pk_f16_f32), lo = RNE(v - hi) as one
-// v_fma_mixlo_f16 / v_fma_mixhi_f16 each (f16 source, f32 addend, f16 result into one half of the destination)
-__device__ __forceinline__ void split_pair(float vx, float vy, unsigned* hi, unsigned* lo) {
-    typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
-    const h2_t h = {(_Float16)vx, (_Float16)vy};
-    const unsigned hb = __builtin_bit_cast(unsigned, h);
-    unsigned l;
-    asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(l) : "v"(hb), "v"(vx));
-    asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(l) : "v"(hb), "v"(vy));
-    *hi = hb;
-    *lo = l;
-}
-
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
-
-__device__ __forceinline__ f16x8 as_h8(f32x4 v) { return __builtin_bit_cast(f16x8, v); }
-
-// value of a split-f16 element: (float)hi.half[SEL] + (float)lo.half[SEL] in ONE instruction (v_fma_mix_f32 reads
-// f16 halves of 32-bit registers as sources of an f32 fma; the compiler spends two conversions and an add on it)
-template <int SEL> __device__ __forceinline__ float unsplit_mix(float hi_pair, float lo_pair) {
-    float d;
-    if constexpr (SEL == 0) asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,1]" : "=v"(d) : "v"(hi_pair), "v"(lo_pair));
-    else asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[1,0,1] op_sel_hi:[1,0,1]" : "=v"(d) : "v"(hi_pair), "v"(lo_pair));
-    return d;
-}
 }  // namespace
 
 // Epilogue of a consumer thread: the wave's accumulator tiles M_p go to LDS, then the thread = (tile-pixel q, 8
