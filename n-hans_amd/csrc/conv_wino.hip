@@ -428,12 +428,13 @@ __global__ void __launch_bounds__(XW * 64) conv_wino(const ConvArgs a) {
 
     // ---- epilogue in two passes of 64 tile-pixels (the eight M_p tiles of a pass are 136 KB of LDS) ----
     long long es[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-#define X_EPI(IDM)                                                                                 \
+#define X_EPI2(IDM, OUTS)                                                                          \
     {                                                                                              \
-        wino_epilogue<IDM, MO>(a, acc, smem, p, lane, tid, b, nb, r0, j0, TR, TJ, cbx, DBG ? es : nullptr, 0, true); \
+        wino_epilogue<IDM, MO, OUTS>(a, acc, smem, p, lane, tid, b, nb, r0, j0, TR, TJ, cbx, DBG ? es : nullptr, 0, true); \
         __builtin_amdgcn_s_barrier();                                                              \
-        wino_epilogue<IDM, MO>(a, acc + 2, smem, p, lane, tid, b, nb, r0, j0, TR, TJ, cbx, DBG ? es + 8 : nullptr, 64, false); \
+        wino_epilogue<IDM, MO, OUTS>(a, acc + 2, smem, p, lane, tid, b, nb, r0, j0, TR, TJ, cbx, DBG ? es + 8 : nullptr, 64, false); \
     }
+#define X_EPI(IDM) { if (a.out_split) X_EPI2(IDM, 1) else X_EPI2(IDM, 0) }
     switch (a.id_mode) {
         case 0: X_EPI(0) break;
         case 1:
@@ -442,6 +443,7 @@ __global__ void __launch_bounds__(XW * 64) conv_wino(const ConvArgs a) {
         default: X_EPI(3) break;
     }
 #undef X_EPI
+#undef X_EPI2
     if constexpr (DBG) {                                                // [K loop, prologue, epilogue, barrier waits in the loop]
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (a.dbg && lane == 0) {

@@ -34,7 +34,7 @@ constexpr size_t kWinoLdsEpi = (size_t)(8 * 64 * W_LDM + (2 + 64) * 64) * sizeof
 //     with s_waitcnt vmcnt(0) -- one full memory latency per column, 2,750 cycles each, was what round 3's first
 //     version of this sweep spent.
 // IDM: 0 no residual, 1 split-NHWC tensor, 2 f32 NHWC tensor, 3 one-channel image.
-template <int IDM, int MO>
+template <int IDM, int MO, int OUTS>       // OUTS: the output is split NHWC (1) or f32 NHWC (0: no split on the way out)
 __device__ __forceinline__ void wino_epilogue(const ConvArgs& a, const f32x16 (*acc)[2], float* ct, int p, int lane, int tid,
                                               int b, int nb, int r0, int j0, int TR, int TJ, int cx, long long* es,
                                               int qbase = 0, bool first = true) {
@@ -210,7 +210,6 @@ __device__ __forceinline__ void wino_epilogue(const ConvArgs& a, const f32x16 (*
     asm volatile("" : "+v"(n_again));
     const uint32_t oo0 = (uint32_t)pix0 * (uint32_t)a.ldo * 4u + (uint32_t)((n_again >> 5) * 64 + (n_again & 31)) * 2u, ost = (uint32_t)a.ldo * 4u;
     const uint32_t oo0f = (uint32_t)pix0 * (uint32_t)a.ldo * 4u + (uint32_t)n_again * 4u;
-    const bool osplit = a.out_split != 0;
     int sat = 0;
 #pragma unroll
     for (int i = 0; i < MO; ++i) {
@@ -242,27 +241,30 @@ __device__ __forceinline__ void wino_epilogue(const ConvArgs& a, const f32x16 (*
         }
         sat |= (over && valid) ? 1 : 0;
         asm volatile("" : "+v"(sat));                       // (here, not after the loop: the compiler would keep all 8*MO values alive for it)
-        uint4 hb, lb;
-        split_pair(yc[0], yc[1], &hb.x, &lb.x);
-        split_pair(yc[2], yc[3], &hb.y, &lb.y);
-        split_pair(yc[4], yc[5], &hb.z, &lb.z);
-        split_pair(yc[6], yc[7], &hb.w, &lb.w);
         // The two stores of a column are UNCONDITIONAL buffer stores (an invalid column's offset lies beyond the frame: the
         // range check of the descriptor drops it): behind an `if (valid)` the compiler's count of stores in flight is a
         // guess, and the next column's table wait became "all earlier stores have completed".
         // Output layout: split NHWC (16 bytes of hi halves, 16 of lo halves, 64 apart) or, for a tensor that only
-        // Winograd launches read, f32 NHWC (the 8 channels' 32 contiguous bytes; the same scaled, clamped values) --
-        // chosen by selects, not by a branch, for the same reason.
+        // Winograd launches read, f32 NHWC (the 8 channels' 32 contiguous bytes; the same scaled, clamped values).
         {
             typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
             const bool ok = valid && !(kDev && (a.wino_m >> 8 & 8));
-            const uint32_t so = ok ? (osplit ? oo0 : oo0f) + (uint32_t)i * ost : 0x80000000u;
-            const u32x4 d0 = osplit ? u32x4{hb.x, hb.y, hb.z, hb.w}
-                                    : u32x4{__builtin_bit_cast(unsigned, yc[0]), __builtin_bit_cast(unsigned, yc[1]), __builtin_bit_cast(unsigned, yc[2]), __builtin_bit_cast(unsigned, yc[3])};
-            const u32x4 d1 = osplit ? u32x4{lb.x, lb.y, lb.z, lb.w}
-                                    : u32x4{__builtin_bit_cast(unsigned, yc[4]), __builtin_bit_cast(unsigned, yc[5]), __builtin_bit_cast(unsigned, yc[6]), __builtin_bit_cast(unsigned, yc[7])};
+            const uint32_t so = ok ? (OUTS ? oo0 : oo0f) + (uint32_t)i * ost : 0x80000000u;
+            u32x4 d0, d1;
+            if constexpr (OUTS) {
+                uint4 hb, lb;
+                split_pair(yc[0], yc[1], &hb.x, &lb.x);
+                split_pair(yc[2], yc[3], &hb.y, &lb.y);
+                split_pair(yc[4], yc[5], &hb.z, &lb.z);
+                split_pair(yc[6], yc[7], &hb.w, &lb.w);
+                d0 = u32x4{hb.x, hb.y, hb.z, hb.w};
+                d1 = u32x4{lb.x, lb.y, lb.z, lb.w};
+            } else {
+                d0 = u32x4{__builtin_bit_cast(unsigned, yc[0]), __builtin_bit_cast(unsigned, yc[1]), __builtin_bit_cast(unsigned, yc[2]), __builtin_bit_cast(unsigned, yc[3])};
+                d1 = u32x4{__builtin_bit_cast(unsigned, yc[4]), __builtin_bit_cast(unsigned, yc[5]), __builtin_bit_cast(unsigned, yc[6]), __builtin_bit_cast(unsigned, yc[7])};
+            }
             __builtin_amdgcn_raw_buffer_store_b128(d0, orsrc, so, 0, 2);          // (2 = nt: written once, read by the next launch)
-            __builtin_amdgcn_raw_buffer_store_b128(d1, orsrc, so + (osplit ? 64u : 16u), 0, 2);
+            __builtin_amdgcn_raw_buffer_store_b128(d1, orsrc, so + (OUTS ? 64u : 16u), 0, 2);
         }
         __builtin_amdgcn_sched_barrier(0);                     // (column by column: bounded register pressure)
     }
