@@ -93,9 +93,14 @@ __global__ void __launch_bounds__(XW * 64) conv_wino(const ConvArgs a) {
     const bool early = wave < XW / 2;            // (uniform) multiplies first, transforms afterwards
 
     // ---- staging: this wave's X_DPW of the tile's X_NDMA LDS-DMA instructions (instruction i = wave + 8k) ----
-    // piece q = 64 i + lane = (kind, row, pixel); byte offset within the frame for chunk 0, or ~0: padding / unused
-    const char* const fbp = reinterpret_cast<const char*>(g.src + (size_t)b * g.H * g.W * C);
-    const char* const zp = reinterpret_cast<const char*>(a.zero + lane * 4);
+    // piece q = 64 i + lane = (kind, row, pixel); byte offset within the frame for chunk 0, or an offset beyond the frame:
+    // padding / unused.  The requests go through a buffer descriptor over the frame: a lane whose offset is out of range
+    // gets ZEROS written to LDS (tools/ubench/buffer_lds_oob.hip) -- padding needs no zero page and no pointer select,
+    // the chunk's offset rides in the scalar offset: one v_cndmask per request (a chunk past the end) where the
+    // 64-bit pointer arithmetic and selects were five VALU instructions, in the phase that sets the period.
+    constexpr unsigned kOob = 0x80000000u;
+    const __amdgpu_buffer_rsrc_t frsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(g.src + (size_t)b * g.H * g.W * C), 0, g.H * g.W * C * 4, 0x00020000);
     unsigned goff[X_DPW];
 #pragma unroll
     for (int k = 0; k < X_DPW; ++k) {
@@ -106,10 +111,10 @@ __global__ void __launch_bounds__(XW * 64) conv_wino(const ConvArgs a) {
         const bool ok = kind < 2 && row < nrows && px < TJ * MO + KH - 1 && (unsigned)hrow < (unsigned)g.H && (unsigned)wcol < (unsigned)g.W;
         // split NHWC: a 32-channel group of a pixel is 64 B of hi halfs followed by 64 B of lo halfs
         // (f32 NHWC: the chunk's 8 channels are 32 contiguous bytes, kind = their first | second 16)
-        goff[k] = ok ? (unsigned)(((hrow * g.W + wcol) * C) * 4 + kind * (INF ? 16 : 64)) : 0xFFFFFFFFu;
+        goff[k] = ok ? (unsigned)(((hrow * g.W + wcol) * C) * 4 + kind * (INF ? 16 : 64)) : kOob;
     }
     const bool last_real = wave + XW * (X_DPW - 1) < X_NDMA;     // (uniform) the wave's last slot carries pieces
-    // tile of chunk CC -> staged buffer RB (a chunk past the end: nothing, into the dump area)
+    // tile of chunk CC -> staged buffer RB (a chunk past the end: zeros into the dump area, no memory read)
 #define X_DMA2(CC, RB, K0)                                                                         \
     {                                                                                              \
         const int cc_ = (CC);                                                                      \
@@ -117,10 +122,9 @@ __global__ void __launch_bounds__(XW * 64) conv_wino(const ConvArgs a) {
         const unsigned co_ = INF ? (unsigned)(cc_ * 32) : (unsigned)((cc_ >> 2) * 128 + (cc_ & 3) * 16); \
         float* const dst_ = smem + X_RAW_BASE + (RB) * X_RAW + wave * 256;                         \
         _Pragma("unroll") for (int k = (K0); k < (K0) + 2; ++k) {                                  \
-            const char* s_ = (goff[k] != 0xFFFFFFFFu && live_) ? fbp + (goff[k] + co_) : zp;       \
             float* d_ = (cc_ < NC && (k < X_DPW - 1 || last_real)) ? dst_ + k * XW * 256 : smem + X_DUMP; \
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)s_,   \
-                                             (__attribute__((address_space(3))) void*)d_, 16, 0, 0); \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(frsrc, (__attribute__((address_space(3))) void*)d_, 16, \
+                                                     live_ ? goff[k] : kOob, live_ ? (int)co_ : 0, 0, 0); \
         }                                                                                          \
     }
 #define X_DMA(CC, RB) { X_DMA2(CC, RB, 0) X_DMA2(CC, RB, 2) }
