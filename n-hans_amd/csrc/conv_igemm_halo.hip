@@ -157,13 +157,25 @@ __global__ void __launch_bounds__((NCW + NPW) * 64) conv_igemm_halo(const ConvAr
         // {r..r+3, r+12..r+15, r+20..r+27} of one fragment, and f = (row>>1)&7 makes those 16 slots
         // distinct for any r.  Per row: element offset of its pixel for kh = 0 / chunk 0 and the input
         // row hi0 of kh = 0, or a sentinel for padding / unused rows.
+        // The image requests go through a buffer descriptor over the input from the tile's first frame on: a lane whose
+        // offset is out of range gets zeros written to LDS (tools/ubench/buffer_lds_oob.hip), padding needs no zero
+        // page, a request no 64-bit pointer arithmetic and select.  (The tap's shift is added per lane, not passed as the
+        // scalar offset: a padding row's own offset is negative and becomes valid only with the shift.)
+        constexpr unsigned kOob = 0x80000000u;
+        const int b0 = (int)fd_div((uint32_t)m0, a.fdHoWo);                      // (uniform) frame of the tile's first pixel
         int poff[NAPW], hov[NAPW], wiv[PWM ? NAPW : 1];
         int sH = 0, sW = 0, sC = 0;
-        const float* ssrc = nullptr;
+        __amdgpu_buffer_rsrc_t srsrc;
 #define NH_MAP_SEGMENT(S)                                                                          \
     {                                                                                              \
         const ConvSeg& g = a.seg[S];                                                               \
-        sH = g.H; sW = g.W; sC = g.C; ssrc = g.src;                                                \
+        sH = g.H; sW = g.W; sC = g.C;                                                              \
+        {                                                                                          \
+            const size_t fb_ = (size_t)g.H * g.W * g.C * 4;                                        \
+            const size_t left_ = (size_t)(a.M / (a.Ho * Wo) - b0) * fb_;                           \
+            srsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.src) + (size_t)b0 * (fb_ / 4), 0, \
+                                                      (int)(left_ < 0x7FFFFFFFu ? left_ : 0x7FFFFFFFu), 0x00020000); \
+        }                                                                                          \
         _Pragma("unroll") for (int d = 0; d < NAPW; ++d) {                                         \
             const int j = d * 32 + pw * 8 + (lane >> 3);                                           \
             const int sp = (slot ^ ((j >> 1) & 7)) * 4;                                            \
@@ -190,7 +202,7 @@ __global__ void __launch_bounds__((NCW + NPW) * 64) conv_igemm_halo(const ConvAr
             if (!ok) { Rg = 0; wi = 0; }                                                           \
             const int b = (int)fd_div((uint32_t)(Rg * Wo), a.fdHoWo);                              \
             const int hi0 = (Rg - b * a.Ho) * g.sh - g.pt;                                         \
-            poff[d] = ((b * g.H + hi0) * g.W + wi) * g.C + sp;                                     \
+            poff[d] = ((((b - b0) * g.H + hi0) * g.W + wi) * g.C + sp) * 4;     /* bytes from the tile's first frame */ \
             hov[d] = ok ? hi0 : -(1 << 28);                                                        \
             if constexpr (PWM) wiv[d] = wi;              /* (column validity depends on the tap's kw) */ \
         }                                                                                          \
@@ -201,7 +213,6 @@ __global__ void __launch_bounds__((NCW + NPW) * 64) conv_igemm_halo(const ConvAr
 
         // activation cursor: next super-chunk to stage
         int segA = 0, khA = 0, ccA = 0, supA = 0, kwA = 0;
-        const float* const zp = a.zero + (slot ^ ((lane >> 4) & 7)) * 4;   // any in-page offset will do
 #define NH_ISSUE_A(BUF)                                                                            \
     {                                                                                              \
         const int khoff_ = (khA * sW + (PWM ? kwA : 0)) * sC + ccA * 32;                           \
@@ -210,8 +221,9 @@ __global__ void __launch_bounds__((NCW + NPW) * 64) conv_igemm_halo(const ConvAr
         _Pragma("unroll") for (int d = 0; d < NAPW; ++d) {                                         \
             bool in_ = !(ABL & 1) && live_ && (unsigned)(hov[d] + khA) < (unsigned)sH;             \
             if constexpr (PWM) in_ = in_ && (unsigned)(wiv[d] + kwA) < (unsigned)sW;               \
-            const float* p_ = in_ ? ssrc + (poff[d] + khoff_) : zp;                                \
-            if constexpr (!(ABL & 2)) NH_GLDS(p_, sa_ + d * 32 * 32)                               \
+            if constexpr (!(ABL & 2))                                                              \
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(srsrc, (__attribute__((address_space(3))) void*)(sa_ + d * 32 * 32), 16, \
+                                                         in_ ? (unsigned)(poff[d] + khoff_ * 4) : kOob, 0, 0, 0); \
         }                                                                                          \
         ++supA;                                                                                    \
         if (PWM && ++kwA < KW0) {                 /* pointwise: the KW taps of a filter row first */ \
