@@ -241,16 +241,25 @@ __global__ void __launch_bounds__((NCW + NPW) * 64) conv_igemm_halo(const ConvAr
         // weight cursor: the next tap is the next `bstride` floats, with one jump to the transform's
         // array and a stall on the last chunk for the dummy loads past the end
         int tapB = 0;
-        const float* bp_ = a.seg[0].wpk + (size_t)nt0 * 1024 - bstride;
-        const float* const wpk1 = (nseg > 1 ? a.seg[1].wpk : a.seg[0].wpk) + (size_t)nt0 * 1024;
+        // (through buffer descriptors as well: the thread's 16 bytes of a tap's block at a fixed per-lane offset, the
+        // tap in the scalar offset -- no per-request address arithmetic at all)
+        const __amdgpu_buffer_rsrc_t wr0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.seg[0].wpk) + (size_t)nt0 * 1024, 0, 0x7FFFFFFF, 0x00020000);
+        const __amdgpu_buffer_rsrc_t wr1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(nseg > 1 ? a.seg[1].wpk : a.seg[0].wpk) + (size_t)nt0 * 1024, 0, 0x7FFFFFFF, 0x00020000);
+        const unsigned wvo = (unsigned)ptid * 16u;
+        const int bstride_b = (int)(bstride * 4);
+        int wtap = -1, wseg = 0;                        // tap within its segment's array (the last one again past the end)
 #define NH_ISSUE_B(ST)                                                                             \
     {                                                                                              \
-        const float* nx_ = tapB == ntap0 ? wpk1 : bp_ + bstride;                                   \
-        bp_ = (tapB < total && !(ABL & 4)) ? nx_ : bp_;                                            \
+        if (tapB < total && !(ABL & 4)) {                                                          \
+            if (tapB == ntap0) { wseg = 1; wtap = 0; } else ++wtap;                                \
+        }                                                                                          \
         ++tapB;                                                                                    \
         float* sb_ = smem + B_BASE + (ST) * B_STAGE;                                               \
+        const int so_ = (ABL & 4) ? 0 : wtap * bstride_b;                                          \
         _Pragma("unroll") for (int j = 0; j < GBP; ++j)                                            \
-            if constexpr (!(ABL & 8)) NH_GLDS((ABL & 4 ? wpk1 : bp_) + (j * (NPW * 64) + ptid) * 4, sb_ + (j * (NPW * 64) + pw * 64) * 4) \
+            if constexpr (!(ABL & 8))                                                              \
+                __builtin_amdgcn_raw_ptr_buffer_load_lds((wseg || (ABL & 4)) ? wr1 : wr0,          \
+                    (__attribute__((address_space(3))) void*)(sb_ + (j * (NPW * 64) + pw * 64) * 4), 16, wvo, so_ + j * (NPW * 64) * 16, 0, 0); \
     }
 
         NH_MAP_SEGMENT(0)
