@@ -387,6 +387,13 @@ __global__ void __launch_bounds__(XW * 64) conv_wino(const ConvArgs a) {
         if (early) X_MULTIPLY(VB, c_ + 1, last_)                                                   \
         X_STAMP(dbg_mult)                                                                          \
         __builtin_amdgcn_sched_barrier(0);                                                         \
+        /* The waves that multiply second request the tile of chunk c + 3 HERE, at the start of the period (its staged  */ \
+        /* buffer was read by the transform of the period before), not behind their multiply at the period's end: the  */ \
+        /* request is then a period and a half old when the transform of chunk c + 3 needs it -- issued at the end, it */ \
+        /* was one period old against an HBM latency of about that under load, and these waves, whose chain is the     */ \
+        /* period, waited ~ 700 cycles for it at every period's end.  (Order in the queue: tile c+3 | weights: the     */ \
+        /* counts of the two waits do not change.)                                                                    */ \
+        if (!early && more_) X_DMA(c_ + 3, rb3)                                                    \
         if (more_) {                                                                               \
             __builtin_amdgcn_s_setprio(2);                                                         \
             if constexpr (DBG) dbg_tq = (long long)__builtin_amdgcn_s_memtime();                   \
@@ -396,11 +403,12 @@ __global__ void __launch_bounds__(XW * 64) conv_wino(const ConvArgs a) {
         X_STAMP(dbg_xf)                                                                            \
         __builtin_amdgcn_sched_barrier(0);                                                         \
         if (!early) {                                                                              \
+            /* (the multiply block's vmcnt(4) stands for "the weights, but not the tile request behind them"; in the   */ \
+            /* last period these waves have sent no tile request, the four youngest are weights)                      */ \
+            if (!more_) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                           \
             X_MULTIPLY(VB, c_ + 1, last_)                                                          \
             X_STAMP(dbg_mult)                                                                      \
             X_LOAD_B1C(c_ + 1, last_)                                                              \
-            __builtin_amdgcn_sched_barrier(0);                                                     \
-            if (more_) X_DMA(c_ + 3, rb3)                                                          \
         }                                                                                          \
         asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)" ::: "memory");                               \
         X_STAMP(dbg_wait)                                                                          \
