@@ -527,3 +527,60 @@ def test_winograd_kernel_isa_keeps_its_hand_counted_waits():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_wino_isa.py")], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "OK" in r.stdout
+
+
+def test_winograd_kernel_wait_counts_by_model():
+    """The counts of conv_wino.hip's hand-written `s_waitcnt vmcnt(N)` restated as a queue model (requests of a wave return
+    in order; `vmcnt(N)` = at most the N youngest may still be in flight) and checked for both kinds of wave and every
+    chunk count: when a multiply block starts, the chunk's 8 weight requests have landed; when a period ends, the tile
+    the NEXT period transforms has.  The ISA check looks at registers, not at counts: the first version of "the
+    second-multiplying waves request their tile at the start of the period" passed it and let the last chunk's k-step-1
+    weights stay in flight (round 4; the bitwise-reproducibility test caught it on the GPU).  The schedule below is the
+    order of the macros in X_PERIOD / the prologue; change both together."""
+    def run(nc, early):
+        q, done = [], set()                      # in-flight requests in issue order; landed tags
+
+        def issue(tag, n):
+            q.extend([tag] * n)
+
+        def wait(n):
+            while len(q) > n:
+                done.add(q.pop(0))
+        # prologue: tile 0, wait; transform chunk 0 with all of chunk 0's weights and tile 1 behind it; tile 2; wait for tile 1
+        issue(("tile", 0), 4); wait(0)
+        issue(("w", 0), 8); issue(("tile", 1), 4); issue(("tile", 2), 4)
+        wait(4)
+        assert ("tile", 1) in done and ("w", 0) in done
+        for c in range(nc):
+            more = c + 1 < nc
+
+            def multiply():
+                if not early and not more:
+                    wait(0)
+                wait(4)                              # opens the multiply block
+                assert ("w", c) in done, (nc, early, c, list(q))
+                if more:
+                    issue(("w", c + 1), 4)           # k-step 0 of the next chunk, inside the block
+
+            def transform():
+                if more:
+                    assert ("tile", c + 1) in done, (nc, early, c)
+                    if early:
+                        issue(("w", c + 1), 4)       # k-step 1, then the tile: embedded requests
+                        issue(("tile", c + 3), 4)
+            if early:
+                multiply(); transform()
+            else:
+                if more:
+                    issue(("tile", c + 3), 4)        # at the start of the period
+                transform(); multiply()
+                if more:
+                    issue(("w", c + 1), 4)           # k-step 1
+            wait(12)                                 # end of the period
+            if c + 2 < nc:
+                assert ("tile", c + 2) in done, (nc, early, c)
+        wait(0)
+
+    for nc in (2, 4, 8, 16, 32):
+        for early in (True, False):
+            run(nc, early)
