@@ -548,9 +548,9 @@ def test_winograd_kernel_wait_counts_by_model():
                 done.add(q.pop(0))
         # prologue: tile 0, wait; transform chunk 0 with all of chunk 0's weights and tile 1 behind it; tile 2; wait for tile 1
         issue(("tile", 0), 4); wait(0)
-        issue(("w", 0), 8); issue(("tile", 1), 4); issue(("tile", 2), 4)
+        issue(("w0", 0), 4); issue(("w1", 0), 4); issue(("tile", 1), 4); issue(("tile", 2), 4)
         wait(4)
-        assert ("tile", 1) in done and ("w", 0) in done
+        assert ("tile", 1) in done and ("w0", 0) in done and ("w1", 0) in done
         for c in range(nc):
             more = c + 1 < nc
 
@@ -558,15 +558,15 @@ def test_winograd_kernel_wait_counts_by_model():
                 if not early and not more:
                     wait(0)
                 wait(4)                              # opens the multiply block
-                assert ("w", c) in done, (nc, early, c, list(q))
+                assert ("w0", c) in done and ("w1", c) not in q, (nc, early, c, list(q))
                 if more:
-                    issue(("w", c + 1), 4)           # k-step 0 of the next chunk, inside the block
+                    issue(("w0", c + 1), 4)          # k-step 0 of the next chunk, inside the block
 
             def transform():
                 if more:
                     assert ("tile", c + 1) in done, (nc, early, c)
                     if early:
-                        issue(("w", c + 1), 4)       # k-step 1, then the tile: embedded requests
+                        issue(("w1", c + 1), 4)      # k-step 1, then the tile: embedded requests
                         issue(("tile", c + 3), 4)
             if early:
                 multiply(); transform()
@@ -575,7 +575,7 @@ def test_winograd_kernel_wait_counts_by_model():
                     issue(("tile", c + 3), 4)        # at the start of the period
                 transform(); multiply()
                 if more:
-                    issue(("w", c + 1), 4)           # k-step 1
+                    issue(("w1", c + 1), 4)          # k-step 1
             wait(12)                                 # end of the period
             if c + 2 < nc:
                 assert ("tile", c + 2) in done, (nc, early, c)
