@@ -40,11 +40,9 @@ def _rank_imports():
 
 F32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 F16_MFMA_PEAK_TFLOPS = 2500.0     # dense f16 MFMA peak; the split mode executes 3 products per MAC
-F16_MFMA_AT_POWER_CAP_TFLOPS = 1660.0   # round-2 measurement on another box (profiles/r02); reported only as a fallback when
-                                        # --no-ceiling skips the live measurement (nhans_debug_mfma_ceiling) on THIS box
 HBM_PEAK_GBS = 8000.0             # spec; 6,290 GB/s is what a float4 copy achieves (same guide)
 HBM_ACHIEVABLE_GBS = 6290.0
-PMC_SUMMARY = os.path.join("profiles", "r04", "pmc_summary_bench_256clips.json")
+PMC_SUMMARY_NAME = "pmc_summary_bench_256clips.json"      # profiles/rNN/: the newest one whose kernel-source fingerprint is the tree's
 
 
 def parse(argv=None):
@@ -65,7 +63,7 @@ def parse(argv=None):
     p.add_argument("--no-kernel-pass", action="store_true", help="skip the extra profiled pass (rocprofv3 runs)")
     p.add_argument("--ceiling-seconds", type=float, default=2.0,
                    help="length of the register-only f16 MFMA run that measures this box's rate at its power cap")
-    p.add_argument("--no-ceiling", action="store_true", help="skip that measurement (quote the round-2 constant)")
+    p.add_argument("--no-ceiling", action="store_true", help="skip that measurement (peak_at_power_cap is then null: no constant stands in)")
     p.add_argument("--cpu-frames", type=int, default=32, help="frames of the CPU baseline sample")
     p.add_argument("--cpu-threads", type=int, default=0, help="0 = min(host cores, 64)")
     p.add_argument("--force-dist", action="store_true",
@@ -320,20 +318,23 @@ def main(argv=None):
     if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
-    sampler = DeviceSampler(local) if rank == 0 else None
+    # (every rank samples its own socket: eight sockets at 1.3 kW do not hold the same clock, and the whole-job number
+    # is the slowest rank's -- the per-rank figures travel to rank 0 after the timed region, see `per_rank` below)
+    sampler = DeviceSampler(local) if (rank == 0 or not a.share_device0) else None
     if sampler:
         sampler.start()
     t0 = time.perf_counter()
     for _ in range(a.steps):
         res = step()
     torch.cuda.synchronize()
+    dt_own = time.perf_counter() - t0             # this rank's steps, before it waits for the others
     if use_dist:
         dist.barrier()
     dt = time.perf_counter() - t0
     device_state = sampler.stop() if sampler else None
     status = eng.take_status()                  # sticky: covers every step above
     if use_dist:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device="cpu" if a.share_device0 else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
@@ -352,18 +353,30 @@ def main(argv=None):
 
     # what the f16 matrix pipes of THIS box sustain at its power cap, measured right after the workload while the
     # socket is still warm: register-only v_mfma_f32_32x32x16_f16 on random operands (nhans_debug_mfma_ceiling)
+    # (N > 1: every rank measures its own socket, all at the same time -- the condition the timed region ran under)
     ceiling = None
-    if rank == 0 and a.precision == "f16x3" and not a.no_ceiling:
+    if (rank == 0 or not a.share_device0) and a.precision == "f16x3" and not a.no_ceiling:
         from nhans_amd import hip as nh
+        if use_dist and not a.share_device0:
+            dist.barrier()                      # (all sockets start together)
         cs = DeviceSampler(local, period=0.1)
         cs.start()
         ceiling = nh.mfma_ceiling(a.ceiling_seconds, eng._stream())
         ceiling["device_state"] = cs.stop()
         ceiling["seconds"] = a.ceiling_seconds
+    per_rank = None
+    if use_dist:
+        mine = {"rank": rank, "device": local, "ms_per_step": 1e3 * dt_own / a.steps,
+                "sclk_mhz_mean": (device_state or {}).get("sclk_mhz_mean"),
+                "socket_power_w_mean": (device_state or {}).get("socket_power_w_mean"),
+                "peak_at_power_cap_tflops": ceiling["sustained_tflops"] if ceiling else None,
+                "status_flags": status}
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine)
 
     if rank == 0:
         ms_step = 1e3 * dt / a.steps
-        cap_tf = ceiling["sustained_tflops"] if ceiling else (F16_MFMA_AT_POWER_CAP_TFLOPS if a.precision == "f16x3" else None)
+        cap_tf = ceiling["sustained_tflops"] if ceiling else None
         convs = {k: v for k, v in prof.items() if k.startswith("conv_igemm") or k.startswith("conv_wino")}
         conv_ms = sum(v["ms"] for v in convs.values())
         conv_fl = sum(v["flops"] for v in convs.values())
@@ -379,15 +392,21 @@ def main(argv=None):
         # fingerprint of n-hans_amd/csrc + fold.py, tools/pmc_summary.py): a kernel change makes `traffic` null instead of
         # silently stale
         traffic, traffic_src = None, None
-        pmc = os.path.join(ROOT, PMC_SUMMARY)
-        if (a.precision == "f16x3" and a.clips_per_gpu == 256 and a.seconds == 10.0 and a.kind == "denoiser"
-                and os.path.exists(pmc)):
+        import glob
+        pmcs = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9]*", PMC_SUMMARY_NAME)), reverse=True)
+        if a.precision == "f16x3" and a.clips_per_gpu == 256 and a.seconds == 10.0 and a.kind == "denoiser" and pmcs:
             sys.path.insert(0, os.path.join(ROOT, "tools"))
             from pmc_summary import kernel_source_sha16
-            summary = json.load(open(pmc))
-            meta = summary.pop("_meta", {})
-            if meta.get("kernel_source_sha16") != kernel_source_sha16(ROOT):
-                traffic_src = "%s is of other kernel sources (%s): not quoted" % (PMC_SUMMARY, meta.get("commit") or meta.get("kernel_source_sha16"))
+            sha = kernel_source_sha16(ROOT)
+            summary, meta, PMC_SUMMARY = None, {}, os.path.relpath(pmcs[0], ROOT)
+            for f in pmcs:                       # newest round first
+                cand = json.load(open(f))
+                m = cand.pop("_meta", {})
+                if m.get("kernel_source_sha16") == sha:
+                    summary, meta, PMC_SUMMARY = cand, m, os.path.relpath(f, ROOT)
+                    break
+            if summary is None:
+                traffic_src = "%s (the newest PMC summary) is of other kernel sources: not quoted" % PMC_SUMMARY
             else:
                 rows = [v for k, v in summary.items() if "conv_igemm" in k or "conv_wino" in k]
                 n = sum(v.get("dispatches_pass_c", 0) for v in rows)
@@ -417,8 +436,11 @@ def main(argv=None):
                        + (" (ALL RANKS ON ONE DEVICE, gloo: functional check only)" if a.share_device0 else "")},
             "frames_per_s": world * frames * a.steps / dt,
             "x_realtime_per_gpu": audio_s * a.steps / dt,
-            "status_flags": status,
+            "status_flags": status if per_rank is None else max(r["status_flags"] for r in per_rank),
             "device_state": device_state,
+            # N > 1: each rank's own time for its steps (the whole-job value above is the slowest rank's, barrier to
+            # barrier), the clock and power its socket held and the f16 matrix rate it sustains at its cap
+            "per_rank": per_rank,
             "roofline": {"bound": "mfma", "kernel": "conv_igemm_* + conv_wino (all implicit-GEMM / Winograd conv launches of a step)",
                          "achieved_basis": "algorithmic FLOPs of the DIRECT convolutions (2*M*K*N), whichever form runs them",
                          "achieved": tflops, "peak": peak, "unit": "TFLOP/s", "frac": tflops / peak,
@@ -436,7 +458,7 @@ def main(argv=None):
                          "peak_at_power_cap_source": ("measured in this run on this device: %.1f s of back-to-back "
                                                       "v_mfma_f32_32x32x16_f16 on random register operands after the timed "
                                                       "region (nhans_debug_mfma_ceiling)" % a.ceiling_seconds) if ceiling
-                         else ("constant from profiles/r02/mfma_power_ceiling.txt (another box)" if cap_tf else None),
+                         else "not measured (--no-ceiling or f32 mode): no constant stands in for it",
                          "peak_at_power_cap_run": ceiling,
                          "source": "hipEvents around every launch in one extra pass after the timed region (%.1f ms wall)"
                                    % (kpass_ms or 0.0),

@@ -343,7 +343,7 @@ double launch_conv_igemm(const ConvArgs& a0, hipStream_t s, const char** kernel,
     // an f32-stored input in the split mode is something only conv_wino.hip reads: the caller (nhans_api.hip:
     // stored_f32) decides both from the same predicate; a disagreement must not run a kernel on the wrong layout
     if (a.prec == 1 && a.in_f32 && !(a.variant >= 2 && a.kgroup >= 0 && conv_wino_eligible(a))) {
-        note_launch("conv (f32-stored input without a Winograd form)", hipErrorInvalidValue);
+        note_refusal("conv (f32-stored input without a Winograd form)");
         if (kernel) *kernel = "refused";
         if (mfma_flops) *mfma_flops = 0;
         return 0;

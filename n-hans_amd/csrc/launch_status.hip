@@ -27,6 +27,10 @@ void note_launch(const char* kernel, hipError_t launch_rc) {
     keep(launch_rc, kernel);
 }
 
+// A launch the LIBRARY refuses (arguments it will not run a kernel on): no HIP call failed, so the runtime's sticky
+// per-thread error -- which may hold something the application left there -- is neither read nor cleared.
+void note_refusal(const char* what) { keep(hipErrorInvalidValue, what); }
+
 void set_max_dynamic_lds(const void* fn, size_t bytes, unsigned long long* done_mask, const char* kernel) {
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);

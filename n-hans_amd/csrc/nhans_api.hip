@@ -95,8 +95,14 @@ struct ProfEntry {
 
 }  // namespace
 
+// which convs of the stack ran in their Winograd form in the last chunk (run_stack_chunk)
+struct StackPlan {
+    bool wino[8][3] = {};      // [block][conv 1 | 2]
+};
+
 struct nhans_ctx {
     int kind = 0, device = 0;
+    StackPlan last_plan;
     float* blob_dev = nullptr;
     size_t blob_bytes = 0;
     std::map<std::string, const float*> arr;
@@ -288,28 +294,27 @@ void run_conv(nhans_ctx* c, const ConvArgs& a0, hipStream_t s) {
     p.done(fl, 0, name, mfma);
 }
 
-// Does conv `cv` (1 | 2) of stack block b run in its Winograd form (conv_wino.hip) with the current options?  Then the
-// launch that writes its input raises the saturation flag at kSatLimitWinoInput.
-bool wino_reader(const nhans_ctx* c, int b, int cv) {
-    if (b < 0 || b > 7 || !c->wino || c->prec != 1 || (c->conv_variant >= 0 && c->conv_variant < 2)) return false;
-    const std::string l = "m" + std::to_string(b) + ".c" + std::to_string(cv), n = l + ".wino";
-    // (conv_wino_eligible: the kernel's epilogue reads the position table as its two terms only)
-    if (c->A(l + ".tf") && !(c->A(l + ".tt") && c->A(l + ".ff"))) return false;
-    return c->A(n) && c->A(n + ".ws");
-}
-float sat_limit_for(const nhans_ctx* c, int b, int cv) { return wino_reader(c, b, cv) ? kSatLimitWinoInput : kSatLimitF16; }
+// Which convs of the stack run in their Winograd form (conv_wino.hip), for one chunk of frame windows.  NOT a restatement
+// of the kernel's conditions: run_stack_chunk() builds every launch's ConvArgs twice -- a planning pass that asks
+// conv_wino_eligible() about those very arguments, then the launching pass that takes layouts and saturation limits
+// from the answers (round-4 advisor finding: a second predicate that left out the 32-bit offset bound, aux, kgroup ...
+// could disagree with the kernel, and the producer would already have written the other layout).
+bool wino_form(const ConvArgs& a) { return a.variant >= 2 && a.kgroup >= 0 && conv_wino_eligible(a); }
+float sat_limit_for(const StackPlan& p, int b, int cv) { return b >= 0 && b < 8 && p.wino[b][cv] ? kSatLimitWinoInput : kSatLimitF16; }
 
 // Is stack tensor (block b; cv 0: conv1's output, 1: the block's output) stored as f32 NHWC in the split-f16 mode?  Yes if
 // every launch that reads it is a Winograd launch -- conv_wino.hip reads either layout (its transform works in f32 and
 // re-splits: with an f32 input it has no hi + lo to add up, 64 of its ~215 instructions per chunk), the direct kernels
 // stage split pieces straight into MFMA operands -- and the launch that writes it is direct_conv64 or a Winograd launch.
 // The values are the same scaled, clamped ones a split store would hold to 22 bits; 4 bytes per element either way.
-bool stored_f32(const nhans_ctx* c, int b, int cv) {
+// (wino_f32 == 2, a test value: f32 whatever the readers are -- launch_conv_igemm() must then refuse the reader.)
+bool stored_f32(const nhans_ctx* c, const StackPlan& p, int b, int cv) {
     if (c->prec != 1 || !c->wino_f32 || b < 0 || b > 7) return false;
-    if (cv == 0) return wino_reader(c, b, 2) && (b == 0 || wino_reader(c, b, 1));
+    if (c->wino_f32 == 2) return b < 4 && !(b == 3 && cv == 1);
+    if (cv == 0) return p.wino[b][2] && (b == 0 || p.wino[b][1]);
     if (b == 7) return false;
     const BlockGeo& nx = c->stack[b + 1];             // read by conv1 of the next block and, in an identity block, by its conv2's epilogue
-    return wino_reader(c, b, 2) && wino_reader(c, b + 1, 1) && nx.cin == nx.cout && wino_reader(c, b + 1, 2);
+    return p.wino[b][2] && p.wino[b + 1][1] && nx.cin == nx.cout && p.wino[b + 1][2];
 }
 
 // Calibration tap: the running |x| maximum of tensor `idx` (`words` values, stored in the active precision's layout).
@@ -427,15 +432,32 @@ void stack_take(nhans_ctx* c, int64_t total, int nclips, int64_t wf, StackBufs* 
 
 // Runs blocks [0, upto) for frames [g0, g0+n); returns the buffer holding the last output.
 // upto = 8: whole stack; upto = 9: + last_conv (output in sb.A).
+// Two passes over the same code: pass 0 builds every conv's arguments and records which of them the Winograd kernel
+// accepts (StackPlan), pass 1 builds them again with the tensor layouts and saturation limits that follow from the plan
+// and launches.  A launch whose eligibility differs between the passes is an error, not a fallback.
 float* run_stack_chunk(nhans_ctx* c, const float* logmag, const StackBufs& sb, int64_t g0, int n, int upto,
                        hipStream_t s) {
-    {
+    StackPlan plan;
+    float* result = nullptr;
+    const int* clipmap = sb.f_clip + g0;
+    for (int pass = 0; pass < 2; ++pass) {
+    const bool go = pass == 1;
+    // (pass 0: record; pass 1: the launch must be the one that was planned)
+    auto conv = [&](int b, int cv, const ConvArgs& a) {
+        const bool w = wino_form(a);
+        if (!go) { plan.wino[b][cv] = w; return; }
+        if (w != plan.wino[b][cv]) {
+            note_refusal("stack conv whose Winograd eligibility changed between planning and launch");
+            return;
+        }
+        run_conv(c, a, s);
+    };
+    if (go) {
         Prof pr(c, s, "gather_windows");
         launch_gather_windows(logmag, sb.f_t, sb.f_T, g0, n, sb.xw, s);
         pr.done(0, (double)n * kMixWin * kBins * 8);
     }
     float *x = sb.X, *a1 = sb.A, *y = sb.Y;
-    const int* clipmap = sb.f_clip + g0;
     for (int b = 0; b < 8 && b < upto; ++b) {
         const BlockGeo& g = c->stack[b];
         const std::string p = "m" + std::to_string(b);
@@ -450,12 +472,14 @@ float* run_stack_chunk(nhans_ctx* c, const float* logmag, const StackBufs& sb, i
             d.cb = cb1; d.cb_stride = c->cond_cols; d.img_clip = clipmap;
             d.tf = c->A(p + ".c1.tf"); d.tt = c->A(p + ".c1.tt"); d.ff = c->A(p + ".c1.ff");
             if (!d.tt || !d.ff) d.tt = d.ff = nullptr;
-            d.relu = 1; d.out_split = c->prec && !stored_f32(c, 0, 0); d.sat = c->prec ? c->status_dev : nullptr;
-            d.out_scale = c->down(SA(0, 0)); d.sat_limit = sat_limit_for(c, 0, 2);
+            d.relu = 1; d.out_split = c->prec && !stored_f32(c, plan, 0, 0); d.sat = c->prec ? c->status_dev : nullptr;
+            d.out_scale = c->down(SA(0, 0)); d.sat_limit = sat_limit_for(plan, 0, 2);
             d.fdHoWo = make_fastdiv(g.hout * g.wout); d.fdWo = make_fastdiv(g.wout);
-            Prof pr(c, s, "direct_conv64");
-            launch_direct_conv64(d, s);
-            pr.done(2.0 * d.M * g.kh * g.kw * 64, 0);
+            if (go) {
+                Prof pr(c, s, "direct_conv64");
+                launch_direct_conv64(d, s);
+                pr.done(2.0 * d.M * g.kh * g.kw * 64, 0);
+            }
         } else {
             ConvArgs a{};
             fill_epilogue_defaults(c, a);
@@ -467,11 +491,11 @@ float* run_stack_chunk(nhans_ctx* c, const float* logmag, const StackBufs& sb, i
             a.ws = c->WS(p + ".c1");
             a.wino_u = c->A(p + ".c1.wino"); a.wino_ws = c->A(p + ".c1.wino.ws");
             a.in_scale = c->up(SA(b - 1, 1)); a.out_scale = c->down(SA(b, 0));
-            a.sat_limit = sat_limit_for(c, b, 2);
-            a.in_f32 = stored_f32(c, b - 1, 1); a.out_split = c->prec && !stored_f32(c, b, 0);
-            run_conv(c, a, s);
+            a.sat_limit = sat_limit_for(plan, b, 2);
+            a.in_f32 = stored_f32(c, plan, b - 1, 1); a.out_split = c->prec && !stored_f32(c, plan, b, 0);
+            conv(b, 1, a);
         }
-        tap(c, SA(b, 0), a1, (size_t)n * g.hout * g.wout * g.cout, s, stored_f32(c, b, 0));
+        if (go) tap(c, SA(b, 0), a1, (size_t)n * g.hout * g.wout * g.cout, s, stored_f32(c, plan, b, 0));
         ConvArgs a{};
         fill_epilogue_defaults(c, a);
         a.nseg = 1;
@@ -482,45 +506,51 @@ float* run_stack_chunk(nhans_ctx* c, const float* logmag, const StackBufs& sb, i
         a.ws = c->WS(p + ".c2");
         a.wino_u = c->A(p + ".c2.wino"); a.wino_ws = c->A(p + ".c2.wino.ws");
         a.in_scale = c->up(SA(b, 0)); a.out_scale = c->down(SA(b, 1));
-        a.sat_limit = sat_limit_for(c, b + 1, 1);
-        a.in_f32 = stored_f32(c, b, 0); a.out_split = c->prec && !stored_f32(c, b, 1);
+        a.sat_limit = sat_limit_for(plan, b + 1, 1);
+        a.in_f32 = stored_f32(c, plan, b, 0); a.out_split = c->prec && !stored_f32(c, plan, b, 1);
         float* out;
         if (b == 0) {                       // 1 -> 64 transform on the window image itself
             a.id_mode = 2; a.id = sb.xw; a.idH = g.hin; a.idW = g.win; a.idsh = 1; a.idsw = 1;
             out = x;
         } else if (g.cin == g.cout) {       // identity shortcut, written in place over the block input
-            a.id_mode = 1; a.id = x; a.id_ld = g.cout; a.id_split = c->prec && !stored_f32(c, b - 1, 1);
+            a.id_mode = 1; a.id = x; a.id_ld = g.cout; a.id_split = c->prec && !stored_f32(c, plan, b - 1, 1);
             a.id_scale = c->up(SA(b - 1, 1));
             // (in place only if input and output share a layout: a thread's output bytes are its residual bytes then)
-            out = stored_f32(c, b - 1, 1) == stored_f32(c, b, 1) ? x : y;
-        } else if (c->wino && c->prec == 1 && g.kh == 4 && a.variant >= 2 && a.wino_u && a.wino_ws) {
-            // Channel-changing block whose conv2 has a Winograd form: the 1x1 strided `_transform` conv cannot ride in
-            // the K loop of the transformed domain, so it runs first on its own (3 % of the block's MACs) into an f32
-            // tensor that conv2's epilogue then adds like a residual (the bias of both is in conv2's bias row).
-            ConvArgs t{};
-            fill_epilogue_defaults(c, t);
-            t.nseg = 1;
-            t.seg[0] = make_seg(x, c->WP(p + ".c2.wpk_t"), g.hin, g.win, g.cin, 1, 1, g.sh, g.sw, false);
-            set_out_geometry(t, n, g.hout, g.wout, g.cout, g.cout, g.cout, sb.T);
-            t.cb = c->A("zero"); t.cb_stride = 0;
-            t.ws = c->WS(p + ".c2");            // (conv2 and the transform share one column scale: fold.py emit())
-            t.relu = 0; t.out_split = 0;
-            t.in_scale = c->up(SA(b - 1, 1));   // (f32 output: no exponent)
-            run_conv(c, t, s);
-            a.id_mode = 1; a.id = sb.T; a.id_ld = g.cout; a.id_split = 0;
-            a.idw = c->A("head.dense.idw");     // ones
-            out = y;
-        } else {                            // 1x1 strided transform as extra K columns (x and a1 share one exponent)
-            a.nseg = 2;
-            a.seg[1] = make_seg(x, c->WP(p + ".c2.wpk_t"), g.hin, g.win, g.cin, 1, 1, g.sh, g.sw, false);
+            out = stored_f32(c, plan, b - 1, 1) == stored_f32(c, plan, b, 1) ? x : y;
+        } else {
+            // Channel-changing block.  If its conv2 -- as a one-segment conv with an f32 residual tensor -- has a
+            // Winograd form, the 1x1 strided `_transform` conv (which cannot ride in the K loop of the transformed
+            // domain; 3 % of the block's MACs) runs first on its own into an f32 tensor that conv2's epilogue then adds
+            // like a residual (the bias of both is in conv2's bias row).  Otherwise it is extra K columns of conv2.
+            ConvArgs w = a;
+            w.id_mode = 1; w.id = sb.T; w.id_ld = g.cout; w.id_split = 0;
+            w.idw = c->A("head.dense.idw");     // ones
+            set_out_geometry(w, n, g.hout, g.wout, g.cout, g.cout, g.cout, y);
+            if (go ? plan.wino[b][2] : wino_form(w)) {
+                ConvArgs t{};
+                fill_epilogue_defaults(c, t);
+                t.nseg = 1;
+                t.seg[0] = make_seg(x, c->WP(p + ".c2.wpk_t"), g.hin, g.win, g.cin, 1, 1, g.sh, g.sw, false);
+                set_out_geometry(t, n, g.hout, g.wout, g.cout, g.cout, g.cout, sb.T);
+                t.cb = c->A("zero"); t.cb_stride = 0;
+                t.ws = c->WS(p + ".c2");            // (conv2 and the transform share one column scale: fold.py emit())
+                t.relu = 0; t.out_split = 0;
+                t.in_scale = c->up(SA(b - 1, 1));   // (f32 output: no exponent)
+                if (go) run_conv(c, t, s);
+                a = w;
+            } else {                        // (x and a1 share one exponent)
+                a.nseg = 2;
+                a.seg[1] = make_seg(x, c->WP(p + ".c2.wpk_t"), g.hin, g.win, g.cin, 1, 1, g.sh, g.sw, false);
+            }
             out = y;
         }
         set_out_geometry(a, n, g.hout, g.wout, g.cout, g.cout, g.cout, out);
-        run_conv(c, a, s);
-        tap(c, SA(b, 1), out, (size_t)n * g.hout * g.wout * g.cout, s, stored_f32(c, b, 1));
+        conv(b, 2, a);
+        if (go) tap(c, SA(b, 1), out, (size_t)n * g.hout * g.wout * g.cout, s, stored_f32(c, plan, b, 1));
         if (out == y) std::swap(x, y);
     }
-    if (upto >= 9) {                        // last_conv [5,1] VALID + BN + ReLU  (SN/main.py:232-236)
+    result = x;
+    if (upto >= 9 && go) {                  // last_conv [5,1] VALID + BN + ReLU  (SN/main.py:232-236)
         const BlockGeo& g = c->stack[7];
         ConvArgs a{};
         fill_epilogue_defaults(c, a);
@@ -532,9 +562,11 @@ float* run_stack_chunk(nhans_ctx* c, const float* logmag, const StackBufs& sb, i
         a.in_scale = c->up(SA(7, 1)); a.out_scale = c->down(kActHead);
         run_conv(c, a, s);
         tap(c, kActHead, a1, (size_t)n * g.wout * 512, s);
-        return a1;
+        result = a1;
     }
-    return x;
+    }
+    c->last_plan = plan;
+    return result;
 }
 
 int mask_net_impl(nhans_ctx* c, const float* logmag, const int64_t* foff, int nclips, const float* ea,
@@ -953,7 +985,7 @@ int nhans_set_option(nhans_ctx* c, const char* key, int64_t value) {
         }
     }
     else if (k == "winograd") c->wino = value != 0;
-    else if (k == "winograd_f32_tensors") c->wino_f32 = value != 0;
+    else if (k == "winograd_f32_tensors") c->wino_f32 = value == 2 ? 2 : value != 0;
     else if (k == "precision") {
         if (value != 0 && value != 1) return fail(NHANS_EINVAL, "precision must be 0 (f32) or 1 (f16x3)");
         if (value == 1 && !c->A("head.dense.wpk_h"))
@@ -1069,7 +1101,7 @@ static int debug_block_output_body(nhans_ctx* c, const float* logmag, const int6
     size_t per;
     if (block == 8) per = (size_t)26 * 512;
     else per = (size_t)c->stack[block].hout * c->stack[block].wout * c->stack[block].cout;
-    if (c->prec && block < 8 && stored_f32(c, block, 1)) launch_scale_copy(res, per * nframes, c->up(SA(block, 1)), out, s);
+    if (c->prec && block < 8 && stored_f32(c, c->last_plan, block, 1)) launch_scale_copy(res, per * nframes, c->up(SA(block, 1)), out, s);
     else if (c->prec) launch_unsplit(res, (int64_t)nframes * (int64_t)(per / (block == 8 ? 512 : c->stack[block].cout)),
                                 block == 8 ? 512 : c->stack[block].cout, c->up(block == 8 ? kActHead : SA(block, 1)), out, s);
     else HIP_TRY(hipMemcpyAsync(out, res, per * nframes * 4, hipMemcpyDeviceToDevice, s));

@@ -32,6 +32,7 @@ constexpr int dev_ablate() { return 0; }
 // failure of the calling thread is kept until the C-ABI entry point collects it with take_launch_error() and returns
 // NHANS_EHIP.  Nothing is launched silently wrong.
 void note_launch(const char* kernel, hipError_t launch_rc);
+void note_refusal(const char* what);        // a launch the library itself refuses: reported as hipErrorInvalidValue, no HIP state touched
 // hipFuncAttributeMaxDynamicSharedMemorySize is a per-DEVICE attribute: `done_mask` (one static per
 // kernel instantiation) has one bit per device id.
 void set_max_dynamic_lds(const void* fn, size_t bytes, unsigned long long* done_mask, const char* kernel);

@@ -87,18 +87,24 @@ class Engine:
         signal): one f32-mode pass with every tensor's maximum recorded."""
         before = self.precision
         self.set_option("calibrate", 1)
-        self.set_precision("f32")
         try:
+            self.set_precision("f32")
             mix_t, mix_off = self._dev(mixes)
             ca_t, ca_off = self._dev(ctx_a)
             cb_t, cb_off = self._dev(ctx_b)
             self.enhance_device(mix_t, mix_off, ca_t, ca_off, cb_t, cb_off)
         except BaseException:
-            self.set_precision(before)
-            self.set_option("calibrate", 3)          # the pass failed: close the bracket, keep the exponents
+            # the pass failed: close the bracket FIRST (3 = keep the exponents, learn nothing) -- an open bracket keeps
+            # recording maxima on every later call --, then put the precision back; neither may mask the original error
+            try:
+                self.set_option("calibrate", 3)
+            finally:
+                self.set_precision(before)
             raise
-        self.set_precision(before)
-        self.set_option("calibrate", 2 if raise_only else 0)
+        try:
+            self.set_option("calibrate", 2 if raise_only else 0)
+        finally:
+            self.set_precision(before)
         return self.activation_exponents()
 
     def take_status(self):
@@ -196,20 +202,23 @@ class Engine:
             warnings.warn("N-HANS f16x3 path: an activation left the f16 range; batch recomputed in f32 MFMA mode "
                           "and the activation exponents raised")
             self.set_option("calibrate", 1)
-            self.set_precision("f32")
             try:
+                self.set_precision("f32")
                 res = self.enhance_device(mix_t, mix_off, ca_t, ca_off, cb_t, cb_off, want_mixed, taps)
                 self.take_status()
             except BaseException:
-                self.set_precision("f16x3")
-                self.set_option("calibrate", 3)
+                try:
+                    self.set_option("calibrate", 3)      # close the bracket first, then restore the precision
+                finally:
+                    self.set_precision("f16x3")
                 raise
-            self.set_precision("f16x3")
             try:
                 # (raise-only; maxima that are not finite -- the flag is also raised by a NaN / Inf INPUT -- are skipped)
                 self.set_option("calibrate", 2)
             except hip.NhansError as err:          # the f32 result stands whatever the exponent update says
                 warnings.warn("N-HANS: activation exponents not updated after the f32 rerun: %s" % err)
+            finally:
+                self.set_precision("f16x3")
         torch.cuda.synchronize(self.device)
         out = {"denoised_wav": [], "mixed_wav": []}
         den = res["denoised_wav"].cpu().numpy()

@@ -430,7 +430,7 @@ def test_f32_stored_winograd_tensors(_eng_d):
     of resblock1_1 / 1_2 / 2_2 and the block outputs of resblock1_1 / 2_1 -- are stored f32 NHWC instead of split NHWC
     (nhans_api.hip: stored_f32); 0 = every tensor split.  Same golden logits at the same bar either way, the block
     outputs of the debug entry point (which has to know each tensor's layout) agree between the two to the split
-    format's 22 bits, and a layer whose input is f32-stored refuses to run in any other kernel."""
+    format's 22 bits.  (The refusal of a wrong-layout reader: the next test.)"""
     _eng_d.set_precision("f16x3")
     g = load_case("case_exp2")
     lm = torch.from_numpy(g["logmag"]).cuda()
@@ -453,3 +453,30 @@ def test_f32_stored_winograd_tensors(_eng_d):
     for b in range(4):
         a0, a1 = out[0][1][b], out[1][1][b]
         assert a0.shape == a1.shape and np.abs(a0 - a1).max() <= 4e-6 * max(1.0, np.abs(a0).max()), b
+
+
+def test_an_f32_stored_tensor_without_a_winograd_reader_is_refused_not_misread(_eng_d):
+    """The layouts follow from what conv_wino_eligible() says about each launch's own arguments (nhans_api.hip:
+    run_stack_chunk plans, then launches).  Should plan and kernel ever disagree, the reader of an f32-stored tensor must
+    refuse -- a direct kernel would stage f32 words as split halves.  winograd_f32_tensors = 2 is the test value that
+    forces the disagreement (f32 storage whatever the readers are); with the Winograd form off every reader is a direct
+    kernel: the call comes back NHANS_EHIP naming the refusal, and the context works again afterwards."""
+    from nhans_amd import hip
+    _eng_d.set_precision("f16x3")
+    g = load_case("case_exp2")
+    lm = torch.from_numpy(g["logmag"]).cuda()
+    ea = torch.from_numpy(g["emb_a"][None]).cuda()
+    eb = torch.from_numpy(g["emb_b"][None]).cuda()
+    try:
+        _eng_d.set_option("winograd", 0)
+        _eng_d.set_option("winograd_f32_tensors", 2)
+        with pytest.raises(hip.NhansError) as e:
+            _eng_d.mask_net(lm, [0, 308], ea, eb)
+        assert "f32-stored input without a Winograd form" in str(e.value), str(e.value)
+    finally:
+        _eng_d.set_option("winograd_f32_tensors", 1)
+        _eng_d.set_option("winograd", 1)
+    torch.cuda.synchronize()
+    _eng_d.take_status()
+    lg = _eng_d.mask_net(lm, [0, 308], ea, eb)[0].cpu().numpy()
+    assert np.abs(lg - g["logits"]).max() < LOGIT_TOL

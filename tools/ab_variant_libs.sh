@@ -1,11 +1,11 @@
 #!/bin/bash
-# Same-box A/B of the libraries under bin_tmp/variants (tools/build_variant.sh): the default bench alternately with each,
+# Same-box A/B of the libraries under build_ab/variants (tools/build_variant.sh): the default bench alternately with each,
 # ROUNDS times; prints x real-time, ms per step and the conv kernels' ms per step.  Boxes differ by several per cent.
 #     gpurun -- 'bash tools/ab_variant_libs.sh [ROUNDS] [bench flags]'
 rounds=${1:-2}; shift
 mkdir -p gpurun_out/ab
 for r in $(seq $rounds); do
-for lib in bin_tmp/variants/libnhans_*.so; do
+for lib in build_ab/variants/libnhans_*.so; do
   n=$(basename $lib .so); n=${n#libnhans_}
   NHANS_LIB=$PWD/$lib python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-ceiling "$@" > gpurun_out/ab/$n.$r.json 2>gpurun_out/ab/$n.$r.err
   python -c "
