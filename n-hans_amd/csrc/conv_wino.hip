@@ -104,8 +104,12 @@ __global__ void __launch_bounds__(XW * 64) conv_wino(const ConvArgs a) {
     unsigned goff[X_DPW];
 #pragma unroll
     for (int k = 0; k < X_DPW; ++k) {
+        // piece q = (row, pixel, kind): the two pieces of a pixel -- hi | lo halves of a split pixel, 64 B apart in one
+        // 128-byte line; the first | second 16 bytes of an f32 pixel's chunk -- sit in neighbouring lanes, so that a wave
+        // instruction touches 32 lines instead of the 64 of a (kind, row, pixel) order: the L1's work per staged tile
+        // halves at the same bytes (round 5)
         const int q = (wave + XW * k) * 64 + lane;
-        const int kind = q / (X_RROWS * X_RPX), rem = q - kind * (X_RROWS * X_RPX);
+        const int kind = q & 1, rem = q >> 1;
         const int row = rem / X_RPX, px = rem - row * X_RPX;
         const int hrow = r0 + row - g.pt, wcol = j0 * MO - g.pl + px;
         const bool ok = kind < 2 && row < nrows && px < TJ * MO + KH - 1 && (unsigned)hrow < (unsigned)g.H && (unsigned)wcol < (unsigned)g.W;
@@ -138,8 +142,9 @@ __global__ void __launch_bounds__(XW * 64) conv_wino(const ConvArgs a) {
     const int t_slot = t_active ? task >> 1 : 0, t_half = task & 1;
     const int t_rs = t_slot / TJ, t_tj = t_slot - t_rs * TJ;
     // LDS byte addresses (dynamic LDS starts at 0: the kernel has no static LDS)
-    const unsigned t_src = INF ? (unsigned)((X_RAW_BASE + t_half * X_RKIND + (t_rs * X_RPX + t_tj * MO) * 4) * 4)   // f32: the task's 4 channels are one piece kind
-                               : (unsigned)((X_RAW_BASE + (t_rs * X_RPX + t_tj * MO) * 4 + t_half * 2) * 4);   // + RB*X_RAW*4 (+ X_RKIND*4: lo)
+    // staged tile: [row][pixel][kind][16 bytes]
+    const unsigned t_src = INF ? (unsigned)((X_RAW_BASE + ((t_rs * X_RPX + t_tj * MO) * 2 + t_half) * 4) * 4)      // f32: the task's 4 channels are one piece kind
+                               : (unsigned)((X_RAW_BASE + (t_rs * X_RPX + t_tj * MO) * 8 + t_half * 2) * 4);   // + RB*X_RAW*4 (+ 16: lo)
     const unsigned t_dst = (unsigned)((t_slot * 4 + t_half * 2) * 4);                                       // + VB*X_VBUF*4 + (p*2 + h)*X_PLANE*4
     // BT, structured (fold.py: WINO_BT): even and odd parts of rows 1..6 share their sums.  ONE channel at a time, in
     // scalar f32 instructions on purpose: beside a running MFMA stream a packed-f32 instruction (v_pk_fma_f32,
@@ -189,21 +194,21 @@ __global__ void __launch_bounds__(XW * 64) conv_wino(const ConvArgs a) {
            between the requests) */                                                                \
         if constexpr (INF) {                                                                       \
             asm volatile(                                                                          \
-                "ds_read_b128 %0, %8\n ds_read_b128 %1, %8 offset:16\n ds_read_b128 %2, %8 offset:32\n ds_read_b128 %3, %8 offset:48\n" \
-                "ds_read_b128 %4, %8 offset:64\n ds_read_b128 %5, %8 offset:80\n ds_read_b128 %6, %8 offset:96\n ds_read_b128 %7, %8 offset:112\n" \
+                "ds_read_b128 %0, %8\n ds_read_b128 %1, %8 offset:32\n ds_read_b128 %2, %8 offset:64\n ds_read_b128 %3, %8 offset:96\n" \
+                "ds_read_b128 %4, %8 offset:128\n ds_read_b128 %5, %8 offset:160\n ds_read_b128 %6, %8 offset:192\n ds_read_b128 %7, %8 offset:224\n" \
                 "s_waitcnt lgkmcnt(0)"                                                             \
                 : "=&v"(rf_[0]), "=&v"(rf_[1]), "=&v"(rf_[2]), "=&v"(rf_[3]), "=&v"(rf_[4]), "=&v"(rf_[5]), "=&v"(rf_[6]), "=&v"(rf_[7]) \
                 : "v"(rs_) : "memory");                                                            \
         } else {                                                                                   \
             asm volatile(                                                                          \
-                "ds_read_b64 %0, %16\n ds_read_b64 %1, %16 offset:16\n ds_read_b64 %2, %16 offset:32\n ds_read_b64 %3, %16 offset:48\n" \
-                "ds_read_b64 %4, %16 offset:64\n ds_read_b64 %5, %16 offset:80\n ds_read_b64 %6, %16 offset:96\n ds_read_b64 %7, %16 offset:112\n" \
-                "ds_read_b64 %8, %16 offset:%17\n ds_read_b64 %9, %16 offset:%17+16\n ds_read_b64 %10, %16 offset:%17+32\n ds_read_b64 %11, %16 offset:%17+48\n" \
-                "ds_read_b64 %12, %16 offset:%17+64\n ds_read_b64 %13, %16 offset:%17+80\n ds_read_b64 %14, %16 offset:%17+96\n ds_read_b64 %15, %16 offset:%17+112\n" \
+                "ds_read_b64 %0, %16\n ds_read_b64 %1, %16 offset:32\n ds_read_b64 %2, %16 offset:64\n ds_read_b64 %3, %16 offset:96\n" \
+                "ds_read_b64 %4, %16 offset:128\n ds_read_b64 %5, %16 offset:160\n ds_read_b64 %6, %16 offset:192\n ds_read_b64 %7, %16 offset:224\n" \
+                "ds_read_b64 %8, %16 offset:%17\n ds_read_b64 %9, %16 offset:%17+32\n ds_read_b64 %10, %16 offset:%17+64\n ds_read_b64 %11, %16 offset:%17+96\n" \
+                "ds_read_b64 %12, %16 offset:%17+128\n ds_read_b64 %13, %16 offset:%17+160\n ds_read_b64 %14, %16 offset:%17+192\n ds_read_b64 %15, %16 offset:%17+224\n" \
                 "s_waitcnt lgkmcnt(0)"                                                             \
                 : "=&v"(rh_[0]), "=&v"(rh_[1]), "=&v"(rh_[2]), "=&v"(rh_[3]), "=&v"(rh_[4]), "=&v"(rh_[5]), "=&v"(rh_[6]), "=&v"(rh_[7]), \
                   "=&v"(rl_[0]), "=&v"(rl_[1]), "=&v"(rl_[2]), "=&v"(rl_[3]), "=&v"(rl_[4]), "=&v"(rl_[5]), "=&v"(rl_[6]), "=&v"(rl_[7]) \
-                : "v"(rs_), "n"(X_RKIND * 4) : "memory");                                          \
+                : "v"(rs_), "n"(16) : "memory");                                                   \
         }                                                                                          \
         X_TSTAMP(0)                                                                                \
         if ((REQ) == 2) X_LOAD_B2(0, 0, u_)                                                        \

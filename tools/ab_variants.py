@@ -23,6 +23,7 @@ def main():
     p.add_argument("--kind", default="denoiser")
     p.add_argument("--option", default="conv_variant", help="the nhans_set_option key to A/B (values: --variants)")
     a = p.parse_args()
+    bench._rank_imports()
     W = weights.synthetic_weights(a.kind, 7)
     eng = engine.Engine(a.kind, W, precision="f16x3")
     mixes, ca, cb, _ = bench.make_batch(a.kind, 0, a.clips, 10.0, min(a.clips, 8))
