@@ -18,8 +18,9 @@ constexpr size_t kWinoLdsEpi = (size_t)(8 * 64 * W_LDM + (2 + 64) * 64) * sizeof
 
 // Epilogue of a consumer thread: the wave's accumulator tiles M_p go to LDS, then the thread = (tile-pixel q, 8
 // channels) forms its MO output columns and runs the fused block epilogue on them.
-//   * `ct` holds the eight transformed-domain tiles M_p[64 tile-pixels][W_LDM] (channel 8a + 4b + c of a row at float
-//     b*32 + a*4 + c: the eight threads of a tile-pixel read 128 contiguous bytes at a time).  The thread reads its
+//   * `ct` holds the eight transformed-domain tiles M_p[64 tile-pixels][W_LDM] (split output: channel 8a + 4b + c of a row
+//     at float b*32 + a*4 + c; f32 output: channel n at float n -- either way thread c8 finds its two 4-channel pieces at
+//     floats 4 c8 and 32 + 4 c8, and the eight threads of a tile-pixel read 128 contiguous bytes at a time).  The thread reads its
 //     8 x 8 values ONCE and forms all MO columns Y_i = sum_p AT[i][p] M_p with the shared sums of the +-1, +-2, +-1/2
 //     point pairs (18 instead of 8*MO operations per channel), two channels at a time, and applies the first step of
 //     the block epilogue, fma(y, ws, bias), on the spot.
@@ -40,7 +41,13 @@ __device__ __forceinline__ void wino_epilogue(const ConvArgs& a, const f32x16 (*
                                               int qbase = 0, bool first = true) {
     const int g8 = lane >> 5;
     const int c8 = tid & 7, q = tid >> 3;
-    const int n = nb * 64 + c8 * 8;
+    // The thread's 8 channels, as two pieces of 4.  Split-NHWC output: channels 8 c8 .. 8 c8 + 7 (16 bytes of hi halves +
+    // 16 of lo halves per access).  f32 output (round 5): channels 4 c8 .. + 3 and 32 + 4 c8 .. + 3 -- the eight threads
+    // of a tile-pixel then cover one whole 128-byte line per access (residual, position table, store) where 8
+    // contiguous channels per thread made every access touch both lines of the pixel at half use.
+    constexpr int CHA = OUTS ? 8 : 4, CHB = OUTS ? 4 : 32;          // first channel of piece 0 = CHA c8; piece 1 = + CHB
+    const int n = nb * 64 + c8 * CHA;
+    const int n8 = nb * 64 + c8 * 8;                                // (the 8 contiguous channels a head thread fetches constants for)
     const int rr = (q + qbase) / TJ, tt = q + qbase - rr * TJ;
     const int ho = r0 + rr, wo0 = (j0 + tt) * MO;
     const bool okq = rr < TR && ho < a.Ho && j0 + tt < a.wino_ntile;
@@ -71,15 +78,15 @@ __device__ __forceinline__ void wino_epilogue(const ConvArgs& a, const f32x16 (*
     const bool row_head = tt == 0 && rr < TR;
     const bool chan_head = q == 0 && first;
     if (chan_head) {
-        const float* wsp = a.ws + n;
-        const float* idp = IDM != 0 ? a.idw + n : a.zero;
+        const float* wsp = a.ws + n8;
+        const float* idp = IDM != 0 ? a.idw + n8 : a.zero;
         asm volatile("global_load_dwordx4 %0, %4, off\n global_load_dwordx4 %1, %4, off offset:16\n"
                      "global_load_dwordx4 %2, %5, off\n global_load_dwordx4 %3, %5, off offset:16"
                      : "=&v"(ka[0]), "=&v"(ka[1]), "=&v"(ka[2]), "=&v"(ka[3]) : "v"(wsp), "v"(idp) : "memory");
     }
     if (row_head) {
-        const float* ttp = a.tt ? a.tt + (size_t)(ho < a.Ho ? ho : 0) * a.N + n : a.zero;
-        const float* cbp = a.cb + cx + n;
+        const float* ttp = a.tt ? a.tt + (size_t)(ho < a.Ho ? ho : 0) * a.N + n8 : a.zero;
+        const float* cbp = a.cb + cx + n8;
         asm volatile("global_load_dwordx4 %0, %4, off\n global_load_dwordx4 %1, %4, off offset:16\n"
                      "global_load_dwordx4 %2, %5, off\n global_load_dwordx4 %3, %5, off offset:16"
                      : "=&v"(kb[0]), "=&v"(kb[1]), "=&v"(kb[2]), "=&v"(kb[3]) : "v"(cbp), "v"(ttp) : "memory");
@@ -108,7 +115,7 @@ __device__ __forceinline__ void wino_epilogue(const ConvArgs& a, const f32x16 (*
         for (int i = 0; i < MO; ++i) {
             const uint32_t o = o0 + (uint32_t)(i < lastc ? i : lastc) * st;
             rh[i] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(idb + o));
-            rl[i] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(idb + o + 16));
+            rl[i] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(idb + o + CHB * 4));
         }
     } else if constexpr (IDM == 3) {
         const int ids0 = (b * a.idH + (okq ? ho : 0) * a.idsh) * a.idW + (okq ? wo0 : 0) * a.idsw;
@@ -127,7 +134,8 @@ __device__ __forceinline__ void wino_epilogue(const ConvArgs& a, const f32x16 (*
 #pragma unroll
             for (int q4 = 0; q4 < 4; ++q4) {
                 const f32x4 v = {acc[t][j][4 * q4], acc[t][j][4 * q4 + 1], acc[t][j][4 * q4 + 2], acc[t][j][4 * q4 + 3]};
-                *reinterpret_cast<f32x4*>(ct + (p * 64 + t * 32 + (lane & 31)) * W_LDM + g8 * 32 + (j * 4 + q4) * 4) = v;
+                // (lane's quad = channels 32 j + 8 q4 + 4 g8 .. + 3 of the block: row position as documented above)
+                *reinterpret_cast<f32x4*>(ct + (p * 64 + t * 32 + (lane & 31)) * W_LDM + (OUTS ? g8 * 32 + (j * 4 + q4) * 4 : 32 * j + 8 * q4 + 4 * g8)) = v;
             }
     // the constants have landed when at most the residual requests (younger, in order) are in flight
     if constexpr (IDM == 1 || IDM == 2) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * MO) : "memory");
@@ -161,7 +169,7 @@ __device__ __forceinline__ void wino_epilogue(const ConvArgs& a, const f32x16 (*
     auto table = [&](int i) {
         const uint32_t o = to0 + (uint32_t)(i < lastc ? i : lastc) * tst;
         t0[i] = *reinterpret_cast<const f32x4*>(ffb + o);
-        t1[i] = *reinterpret_cast<const f32x4*>(ffb + o + 16 * f_tf);
+        t1[i] = *reinterpret_cast<const f32x4*>(ffb + o + CHB * 4 * f_tf);
     };
     constexpr int TAHEAD = 2;
 #pragma unroll
@@ -174,8 +182,9 @@ __device__ __forceinline__ void wino_epilogue(const ConvArgs& a, const f32x16 (*
         f32x2 m[8];
 #pragma unroll
         for (int pp = 0; pp < 8; ++pp) m[pp] = *reinterpret_cast<const f32x2*>(slot + pp * 64 * W_LDM);
-        const f32x2 ws2 = *reinterpret_cast<const f32x2*>(cst + c8 * 8 + 2 * qt);
-        const f32x2 hc2 = *reinterpret_cast<const f32x2*>(cst + (2 + (rr < TR ? rr : 0)) * 64 + c8 * 8 + 2 * qt);
+        const int cq = c8 * CHA + (qt >> 1) * CHB + (qt & 1) * 2;            // the pair's first channel within the block
+        const f32x2 ws2 = *reinterpret_cast<const f32x2*>(cst + cq);
+        const f32x2 hc2 = *reinterpret_cast<const f32x2*>(cst + (2 + (rr < TR ? rr : 0)) * 64 + cq);
         const f32x2 s12 = m[1] + m[2], d12 = m[1] - m[2], s34 = m[3] + m[4], d34 = m[3] - m[4], s56 = m[5] + m[6], d56 = m[5] - m[6];
         f32x2 y[MO];
         y[0] = (m[0] + s12) + (s34 + s56);
@@ -199,8 +208,8 @@ __device__ __forceinline__ void wino_epilogue(const ConvArgs& a, const f32x16 (*
     // 4. columns
     f32x4 iw0 = {0.f, 0.f, 0.f, 0.f}, iw1 = iw0;
     if constexpr (IDM != 0) {
-        iw0 = *reinterpret_cast<const f32x4*>(cst + 64 + c8 * 8);
-        iw1 = *reinterpret_cast<const f32x4*>(cst + 64 + c8 * 8 + 4);
+        iw0 = *reinterpret_cast<const f32x4*>(cst + 64 + c8 * CHA);
+        iw1 = *reinterpret_cast<const f32x4*>(cst + 64 + c8 * CHA + CHB);
     }
     const float osc = CONV_KARG(out_scale), slim = CONV_KARG(sat_limit);
     char* const outb = reinterpret_cast<char*>(a.out + fpix * a.ldo);
@@ -264,7 +273,7 @@ __device__ __forceinline__ void wino_epilogue(const ConvArgs& a, const f32x16 (*
                 d1 = u32x4{__builtin_bit_cast(unsigned, yc[4]), __builtin_bit_cast(unsigned, yc[5]), __builtin_bit_cast(unsigned, yc[6]), __builtin_bit_cast(unsigned, yc[7])};
             }
             __builtin_amdgcn_raw_buffer_store_b128(d0, orsrc, so, 0, 2);          // (2 = nt: written once, read by the next launch)
-            __builtin_amdgcn_raw_buffer_store_b128(d1, orsrc, so + (OUTS ? 64u : 16u), 0, 2);
+            __builtin_amdgcn_raw_buffer_store_b128(d1, orsrc, so + (OUTS ? 64u : (unsigned)(CHB * 4)), 0, 2);
         }
         __builtin_amdgcn_sched_barrier(0);                     // (column by column: bounded register pressure)
     }
