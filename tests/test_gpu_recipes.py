@@ -4,7 +4,9 @@ Every golden vector of this repo is the oracle on ONE Gaussian draw; the referen
 pointer.  What the split-f16 arithmetic is sensitive to -- columns of very different magnitude under one power-of-two
 scale, `lo` halves near the subnormal range, the Winograd re-split, the activation exponents -- depends on the weight
 distribution, so the network is compared with the float64 oracle (computed here: it travels) on identical features
-for five more recipes, both models, the Winograd form on and off, both arithmetic modes.
+for five more recipes, both models, the Winograd form on and off, both arithmetic modes -- on 20 frames of two clips
+in one call (round 5; three frames before): a clip edge and a chunk boundary inside the batch, every tile-pixel block and
+256-pixel tile of the kernels filled by several frames.
 
 Bar: BASELINE.json's 1e-4 on the mask logits.  That figure belongs to logits of O(5) (the goldens' range: 2e-5 of
 their magnitude); a recipe whose logits are larger is held to the same relative figure, 1e-4 * max(1, max|logit| / 5).
@@ -26,28 +28,55 @@ LOGIT_TOL = 1e-4
 EMB_TOL = 2e-5
 
 
+FRAMES = (11, 9)        # two clips in one call: 20 frames, a clip edge at frame 11
+CHUNK = 16              # frame windows per pass of the stack: a chunk boundary inside the second clip
+
+
 def _features():
-    """Three frames of a mixture (the windows reach the zero padding on both sides) and two 200-frame contexts, as the
-    oracle computes them; float32 is what the C ABI takes, so the oracle continues from the rounded values."""
-    mix = apply.trim_to_frames(apply.normalise(synth.mixture(61, 0.045)))
-    lm = O.logmag_phase(O.stft(mix))[0].astype(np.float32)
-    assert lm.shape[0] == 3
+    """Two short mixtures (11 + 9 frames: every window of a clip reaches its zero padding, the clip edge falls inside a
+    256-pixel tile of the direct kernels -- resblock4 has 130 pixels per frame -- and, with 16 frame windows per chunk,
+    a chunk boundary falls inside the second clip) and two 200-frame contexts, as the oracle computes them; float32 is
+    what the C ABI takes, so the reference continues from the rounded values."""
+    lms = []
+    for i, nfr in enumerate(FRAMES):
+        mix = apply.trim_to_frames(apply.normalise(synth.mixture(61 + i, (400 + (nfr - 1) * 160) / 16000.0)))
+        lm = O.logmag_phase(O.stft(mix))[0].astype(np.float32)
+        assert lm.shape[0] == nfr, lm.shape
+        lms.append(lm)
     ctx = np.stack([O.context(O.logmag_phase(O.stft(apply.normalise(w)))[0]) for w in (synth.noise_context(61), synth.speaker_context(62))])
-    return lm, ctx.astype(np.float32)
+    return lms, ctx.astype(np.float32)
+
+
+def _reference(W, kind, lms, emb_ref):
+    """float64 logits / denoised frames of both clips (clip 0 conditioned on (emb 0, emb 1), clip 1 on (emb 1, emb 0)) by
+    the torch restatement of the reference (oracle/torch_ref.py, float64: equal to oracle/nhans_oracle.py to 1e-9,
+    tests/test_oracle.py -- and fast enough for 20 frames x 5 recipes x 2 models), its windows cut per clip."""
+    from oracle.torch_ref import TorchRef
+    ref = TorchRef(W, kind, torch.float64)
+    outs, dens = [], []
+    with torch.no_grad():
+        for i, lm in enumerate(lms):
+            win = ref.windows(torch.from_numpy(lm).double())
+            ea = torch.from_numpy(emb_ref[i % 2]).double()[None].expand(len(lm), -1)
+            eb = torch.from_numpy(emb_ref[(i + 1) % 2]).double()[None].expand(len(lm), -1)
+            o, d = ref.mask_net(win, ea, eb)
+            outs.append(o.numpy())
+            dens.append(d.numpy())
+    return np.concatenate(outs), np.concatenate(dens)
 
 
 @pytest.mark.parametrize("recipe", sorted(R.RECIPES))
 @pytest.mark.parametrize("kind", ["denoiser", "separator"])
 def test_recipe_against_the_oracle(lib_built, kind, recipe):
     W = R.RECIPES[recipe](kind)
-    lm, ctx = _features()
+    lms, ctx = _features()
     emb_ref = O.embed_tower(ctx.astype(np.float64), W)
-    win = O.strided_crop(lm.astype(np.float64), 35)
-    n = win.shape[0]
-    ref, den_ref = O.mask_net(win, np.tile(emb_ref[0:1], (n, 1)), np.tile(emb_ref[1:2], (n, 1)), W, kind)
+    ref, den_ref = _reference(W, kind, lms, emb_ref)
+    lm = np.concatenate(lms)
+    foff = [0, FRAMES[0], FRAMES[0] + FRAMES[1]]
     tol = LOGIT_TOL * max(1.0, float(np.abs(ref).max()) / 5.0)
     etol = EMB_TOL * max(1.0, float(np.abs(emb_ref).max()))
-    eng = engine.Engine(kind, W, precision="f16x3")
+    eng = engine.Engine(kind, W, precision="f16x3", frames_per_chunk=CHUNK)
     try:
         lm_t = torch.from_numpy(lm).cuda()
         ctx_t = torch.from_numpy(ctx).cuda()
@@ -57,19 +86,20 @@ def test_recipe_against_the_oracle(lib_built, kind, recipe):
             emb = eng.embed(ctx_t)
             st_e = eng.take_status()
             e_err = float(np.abs(emb.cpu().numpy() - emb_ref).max())
-            # identical features for the network: the ORACLE's embeddings, rounded to float32
-            ea = torch.from_numpy(emb_ref[0:1].astype(np.float32)).cuda()
-            eb = torch.from_numpy(emb_ref[1:2].astype(np.float32)).cuda()
+            # identical features for the network: the ORACLE's embeddings, rounded to float32, one pair per clip
+            ea = torch.from_numpy(emb_ref[[0, 1]].astype(np.float32)).cuda()
+            eb = torch.from_numpy(emb_ref[[1, 0]].astype(np.float32)).cuda()
             for wino in (1, 0):
                 eng.set_option("winograd", wino)
-                lg, den = eng.mask_net(lm_t, [0, n], ea, eb)
+                lg, den = eng.mask_net(lm_t, foff, ea, eb)
                 st = eng.take_status()
                 err = float(np.abs(lg.cpu().numpy() - ref).max())
                 derr = float(np.abs(den.cpu().numpy() - den_ref).max())
                 rows.append((prec, wino, st | st_e, e_err, err, derr))
             eng.set_option("winograd", 1)
-        print(kind, recipe, "max|logit| %.3g tol %.2e:" % (np.abs(ref).max(), tol),
-              " ".join("%s/w%d st%d emb %.1e logit %.1e" % r[:5] for r in rows))
+        # (the ABSOLUTE errors beside the bar: the bar scales with the recipe's logit magnitude, the numbers do not)
+        print("%s %s: %d frames, max|logit| %.3g, bar %.2e (1e-4 x max(1, max|logit| / 5)); absolute errors:" % (kind, recipe, len(lm), np.abs(ref).max(), tol),
+              " ".join("%s/w%d st%d emb %.1e logit %.2e" % r[:5] for r in rows))
         f32_rows = [r for r in rows if r[0] == "f32"]
         for prec, wino, st, e_err, err, derr in f32_rows:
             assert st == 0 and e_err < etol and err < tol and derr < tol, (kind, recipe, prec, wino, st, e_err, err)
@@ -83,7 +113,7 @@ def test_recipe_against_the_oracle(lib_built, kind, recipe):
             # the reference's own initialisers: `out` is exactly 0 and `denoised` exactly the centre frame, in every mode
             for prec in ("f16x3", "f32"):
                 eng.set_precision(prec)
-                lg, den = eng.mask_net(lm_t, [0, n], ea, eb)
+                lg, den = eng.mask_net(lm_t, foff, ea, eb)
                 assert not lg.cpu().numpy().any() and np.array_equal(den.cpu().numpy(), lm)
     finally:
         eng.close()

@@ -529,14 +529,66 @@ def test_winograd_kernel_isa_keeps_its_hand_counted_waits():
     assert "OK" in r.stdout
 
 
+def _wino_schedule_from_source():
+    """What the queue model below needs, READ FROM conv_wino.hip instead of restated: the order of the request / wait /
+    multiply / transform events of a period (the token sequence of the X_PERIOD macro), the immediates of the hand-written
+    `s_waitcnt vmcnt(N)`, and how many requests each macro issues (counted in the macros' own text).  A reordered or
+    recounted source changes the model's input -- or fails the structural asserts here -- instead of silently leaving a
+    stale restatement green (round-4 advisor finding)."""
+    src = open(os.path.join(ROOT, "n-hans_amd", "csrc", "conv_wino.hip")).read()
+
+    def macro(name):
+        """text of `#define <name> ...` with its continuation lines"""
+        lines = src.split("\n")
+        i = next(k for k, l in enumerate(lines) if l.startswith("#define " + name))
+        j = i
+        while lines[j].rstrip().endswith("\\"):
+            j += 1
+        return "\n".join(lines[i:j + 1])
+
+    dma2, dma, b2, b2c, b1c, mult, xform, period = (macro(n) for n in ("X_DMA2(CC, RB, K0)", "X_DMA(CC, RB)", "X_LOAD_B2(S, J, UPTR)",
+                                                                          "X_LOAD_B2C(S, J, UPTR, SKIP)", "X_LOAD_B1C(CC, SKIP)",
+                                                                          "X_MULTIPLY(VB, CN, LAST)", "X_TRANSFORM(RB, VB, BC, DC, DB, DO_T, REQ)",
+                                                                          "X_PERIOD(C_, VB)"))
+    n = {}
+    assert dma2.count("raw_ptr_buffer_load_lds") == 1 and "k < (K0) + 2" in dma2
+    n["dma2"] = 2
+    n["dma"] = dma.count("X_DMA2(") * n["dma2"]
+    n["b2"] = b2.count("global_load_dwordx4")
+    assert b2c.count("global_load_dwordx4") == n["b2"]
+    n["b1c"] = b1c.count("X_LOAD_B2C(") * n["b2"]
+    n["mult_loads"] = mult.count("global_load_dwordx4")              # the next chunk's k-step-0 weights, inside the block
+    n["mult_wait"] = int(re.search(r"s_waitcnt vmcnt\((\d+)\)", mult).group(1))
+    # requests of a transform by its REQ argument, from the macro's own conditionals (ep = 0, 1)
+    for want in ("if ((REQ) == 2) X_LOAD_B2(0, 0, u_)", "if (ep == 0) { if ((REQ) == 2) X_LOAD_B2(0, 1, u_) } else if (REQ) { X_DMA2(DC, DB, 0) }",
+                 "if (REQ) { if (ep == 0) { X_LOAD_B2(1, 0, u_) } else { X_DMA2(DC, DB, 2) } }", "if (REQ && ep == 0) { X_LOAD_B2(1, 1, u_) }"):
+        assert want in xform, want
+    # (in issue order) REQ 2: k-step 0 (2 x b2), k-step 1 (2 x b2), then the tile (2 x dma2); REQ 1: k-step 1, the tile
+    n["xform"] = {2: [("w0", 2 * n["b2"]), ("w1", 2 * n["b2"]), ("tile", 2 * n["dma2"])], 1: [("w1", 2 * n["b2"]), ("tile", 2 * n["dma2"])], 0: []}
+    toks = re.findall(r"if \(early\) X_MULTIPLY|if \(!early && more_\) X_DMA\(c_ \+ 3|if \(more_\)|X_TRANSFORM\([^)]*\(early \? 1 : 0\)\)|if \(!early\)|"
+                      r"if \(!more_\) asm volatile\(\"s_waitcnt vmcnt\((\d+)\)\"|X_MULTIPLY\(VB|X_LOAD_B1C\(c_ \+ 1|s_waitcnt vmcnt\((\d+)\) lgkmcnt\(0\)|s_barrier", period)
+    kinds = re.findall(r"if \(early\) X_MULTIPLY|if \(!early && more_\) X_DMA|if \(more_\)|X_TRANSFORM|if \(!early\)|if \(!more_\) asm|X_MULTIPLY\(VB|X_LOAD_B1C|vmcnt\(\d+\) lgkmcnt|s_barrier", period)
+    assert kinds == ["if (early) X_MULTIPLY", "if (!early && more_) X_DMA", "if (more_)", "X_TRANSFORM", "if (!early)", "if (!more_) asm", "X_MULTIPLY(VB",
+                     "X_LOAD_B1C", "vmcnt(12) lgkmcnt" if False else kinds[8], "s_barrier"], kinds
+    n["late_last_wait"] = int([t[0] for t in toks if t[0]][0])
+    n["period_wait"] = int([t[1] for t in toks if t[1]][0])
+    # prologue: X_DMA(0, 0); vmcnt(0); barrier; X_TRANSFORM(0, 0, 0, 1, 1, true, 2); X_DMA(2, 2); vmcnt(N)
+    pro = src[src.index("// ---- prologue: ONLY tile 0"):src.index("// ---- K loop.")]
+    assert re.search(r"X_DMA\(0, 0\)", pro) and "X_TRANSFORM(0, 0, 0, 1, 1, true, 2)" in pro and "X_DMA(2, 2)" in pro
+    n["prologue_wait"] = int(re.findall(r"s_waitcnt vmcnt\((\d+)\) lgkmcnt\(0\)", pro)[0])
+    return n
+
+
 def test_winograd_kernel_wait_counts_by_model():
-    """The counts of conv_wino.hip's hand-written `s_waitcnt vmcnt(N)` restated as a queue model (requests of a wave return
-    in order; `vmcnt(N)` = at most the N youngest may still be in flight) and checked for both kinds of wave and every
-    chunk count: when a multiply block starts, the chunk's 8 weight requests have landed; when a period ends, the tile
-    the NEXT period transforms has.  The ISA check looks at registers, not at counts: the first version of "the
-    second-multiplying waves request their tile at the start of the period" passed it and let the last chunk's k-step-1
-    weights stay in flight (round 4; the bitwise-reproducibility test caught it on the GPU).  The schedule below is the
-    order of the macros in X_PERIOD / the prologue; change both together."""
+    """The counts of conv_wino.hip's hand-written `s_waitcnt vmcnt(N)` as a queue model (requests of a wave return in
+    order; `vmcnt(N)` = at most the N youngest may still be in flight), checked for both kinds of wave and every chunk
+    count: when a multiply block starts, the chunk's 8 weight requests have landed; when a period ends, the tile the NEXT
+    period transforms has.  The ISA check looks at registers, not at counts: the first version of "the second-multiplying
+    waves request their tile at the start of the period" passed it and let the last chunk's k-step-1 weights stay in
+    flight (round 4; the bitwise-reproducibility test caught it on the GPU).  The event order, the wait immediates and the
+    requests per macro come from the SOURCE (_wino_schedule_from_source)."""
+    S = _wino_schedule_from_source()
+
     def run(nc, early):
         q, done = [], set()                      # in-flight requests in issue order; landed tags
 
@@ -546,39 +598,43 @@ def test_winograd_kernel_wait_counts_by_model():
         def wait(n):
             while len(q) > n:
                 done.add(q.pop(0))
+
+        def landed(tag):                             # ALL requests of the tag (a tag has several)
+            return tag in done and tag not in q
         # prologue: tile 0, wait; transform chunk 0 with all of chunk 0's weights and tile 1 behind it; tile 2; wait for tile 1
-        issue(("tile", 0), 4); wait(0)
-        issue(("w0", 0), 4); issue(("w1", 0), 4); issue(("tile", 1), 4); issue(("tile", 2), 4)
-        wait(4)
-        assert ("tile", 1) in done and ("w0", 0) in done and ("w1", 0) in done
+        issue(("tile", 0), S["dma"]); wait(0)
+        for kind, cnt in S["xform"][2]:
+            issue((kind, 0) if kind != "tile" else ("tile", 1), cnt)
+        issue(("tile", 2), S["dma"])
+        wait(S["prologue_wait"])
+        assert landed(("tile", 1)) and landed(("w0", 0)) and landed(("w1", 0))
         for c in range(nc):
             more = c + 1 < nc
 
             def multiply():
                 if not early and not more:
-                    wait(0)
-                wait(4)                              # opens the multiply block
-                assert ("w0", c) in done and ("w1", c) not in q, (nc, early, c, list(q))
+                    wait(S["late_last_wait"])
+                wait(S["mult_wait"])                 # opens the multiply block
+                assert landed(("w0", c)) and landed(("w1", c)), (nc, early, c, list(q))
                 if more:
-                    issue(("w0", c + 1), 4)          # k-step 0 of the next chunk, inside the block
+                    issue(("w0", c + 1), S["mult_loads"])   # k-step 0 of the next chunk, inside the block
 
             def transform():
                 if more:
-                    assert ("tile", c + 1) in done, (nc, early, c)
-                    if early:
-                        issue(("w1", c + 1), 4)      # k-step 1, then the tile: embedded requests
-                        issue(("tile", c + 3), 4)
+                    assert landed(("tile", c + 1)), (nc, early, c)
+                    for kind, cnt in S["xform"][1 if early else 0]:
+                        issue((kind, c + 1) if kind != "tile" else ("tile", c + 3), cnt)
             if early:
                 multiply(); transform()
             else:
                 if more:
-                    issue(("tile", c + 3), 4)        # at the start of the period
+                    issue(("tile", c + 3), S["dma"])  # at the start of the period
                 transform(); multiply()
                 if more:
-                    issue(("w1", c + 1), 4)          # k-step 1
-            wait(12)                                 # end of the period
+                    issue(("w1", c + 1), S["b1c"])    # k-step 1
+            wait(S["period_wait"])                    # end of the period
             if c + 2 < nc:
-                assert ("tile", c + 2) in done, (nc, early, c)
+                assert landed(("tile", c + 2)), (nc, early, c)
         wait(0)
 
     for nc in (2, 4, 8, 16, 32):
