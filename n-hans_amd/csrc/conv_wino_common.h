@@ -93,35 +93,37 @@ __device__ __forceinline__ void wino_epilogue(const ConvArgs& a, const f32x16 (*
     }
     __builtin_amdgcn_sched_barrier(0);
 
-    // 1. residual requests of all columns
+    // 1. residual requests.  Only the first RQ0 columns' go out here, before the accumulators leave for LDS; the others
+    // follow one column per iteration of the output transform (round 5).  A wave that issues all ten requests in one burst
+    // stalls until the CU's vector-memory queue has taken them -- with eight waves doing so at once the burst took 5 k
+    // cycles per wave and pass in which it neither dumped nor transformed (stamps: profiles/r05) -- and the sweep needs
+    // column i's residual only after columns 0 .. i-1 are through.
+    // (non-temporal: the residual is read once and the output written once -- left at the default policy these streams
+    // pushed the input tiles' halo rows and the weights out of the 4 MB L2 before the neighbouring workgroup came for
+    // them: with the hint the 64-channel layers' HBM reads equal their algorithmic bytes)
+    constexpr int RQ0 = 2;
     f32x4 rh[MO], rl[MO];
     float rsv[MO];
-    if constexpr (IDM == 1) {
-        const char* const idb = reinterpret_cast<const char*>(a.id + fpix * a.id_ld);
-        const uint32_t o0 = (uint32_t)pix0 * (uint32_t)a.id_ld * 4u + (uint32_t)hoff * 2u, st = (uint32_t)a.id_ld * 4u;
-#pragma unroll
-        for (int i = 0; i < MO; ++i) {
+    auto residual = [&](int i) {
+        if constexpr (IDM == 1) {
+            const char* const idb = reinterpret_cast<const char*>(a.id + fpix * a.id_ld);
+            const uint32_t o0 = (uint32_t)pix0 * (uint32_t)a.id_ld * 4u + (uint32_t)hoff * 2u, st = (uint32_t)a.id_ld * 4u;
             const uint32_t o = (kDev && (a.wino_m >> 8 & 8)) ? (uint32_t)hoff * 2u : o0 + (uint32_t)(i < lastc ? i : lastc) * st;
-            // non-temporal: the residual is read once and the output written once -- left at the default policy these
-            // streams pushed the input tiles' halo rows (and the weights) out of the 4 MB L2 before the neighbouring
-            // workgroup came for them: with the hint the 64-channel layers' HBM reads equal their algorithmic bytes
             rh[i] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(idb + o));
             rl[i] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(idb + o + 64));
-        }
-    } else if constexpr (IDM == 2) {
-        const char* const idb = reinterpret_cast<const char*>(a.id + fpix * a.id_ld);
-        const uint32_t o0 = ((uint32_t)pix0 * (uint32_t)a.id_ld + (uint32_t)n) * 4u, st = (uint32_t)a.id_ld * 4u;
-#pragma unroll
-        for (int i = 0; i < MO; ++i) {
+        } else if constexpr (IDM == 2) {
+            const char* const idb = reinterpret_cast<const char*>(a.id + fpix * a.id_ld);
+            const uint32_t o0 = ((uint32_t)pix0 * (uint32_t)a.id_ld + (uint32_t)n) * 4u, st = (uint32_t)a.id_ld * 4u;
             const uint32_t o = o0 + (uint32_t)(i < lastc ? i : lastc) * st;
             rh[i] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(idb + o));
             rl[i] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(idb + o + CHB * 4));
+        } else if constexpr (IDM == 3) {
+            const int ids0 = (b * a.idH + (okq ? ho : 0) * a.idsh) * a.idW + (okq ? wo0 : 0) * a.idsw;
+            rsv[i] = a.id[ids0 + (i < lastc ? i : lastc) * a.idsw];
         }
-    } else if constexpr (IDM == 3) {
-        const int ids0 = (b * a.idH + (okq ? ho : 0) * a.idsh) * a.idW + (okq ? wo0 : 0) * a.idsw;
+    };
 #pragma unroll
-        for (int i = 0; i < MO; ++i) rsv[i] = a.id[ids0 + (i < lastc ? i : lastc) * a.idsw];
-    }
+    for (int i = 0; i < RQ0; ++i) residual(i);
     __builtin_amdgcn_sched_barrier(0);
     if (kDev && es) es[4] = (long long)__builtin_amdgcn_s_memtime();
 
@@ -138,8 +140,8 @@ __device__ __forceinline__ void wino_epilogue(const ConvArgs& a, const f32x16 (*
                 *reinterpret_cast<f32x4*>(ct + (p * 64 + t * 32 + (lane & 31)) * W_LDM + (OUTS ? g8 * 32 + (j * 4 + q4) * 4 : 32 * j + 8 * q4 + 4 * g8)) = v;
             }
     // the constants have landed when at most the residual requests (younger, in order) are in flight
-    if constexpr (IDM == 1 || IDM == 2) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * MO) : "memory");
-    else if constexpr (IDM == 3) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(MO) : "memory");
+    if constexpr (IDM == 1 || IDM == 2) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * RQ0) : "memory");
+    else if constexpr (IDM == 3) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(RQ0) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (chan_head) {
         const float in_scale = CONV_KARG(in_scale), id_scale = CONV_KARG(id_scale);
@@ -176,8 +178,10 @@ __device__ __forceinline__ void wino_epilogue(const ConvArgs& a, const f32x16 (*
     for (int i = 0; i < TAHEAD; ++i) table(i);
     __builtin_amdgcn_sched_barrier(0);
     float* const my = ct + q * W_LDM + c8 * 4;                                // + position * 64 * W_LDM + (0 | 32)
+    static_assert(MO - RQ0 <= 4, "one late residual column per transform iteration");
 #pragma unroll
     for (int qt = 0; qt < 4; ++qt) {
+        if (RQ0 + qt < MO) residual(RQ0 + qt);
         float* const slot = my + (qt >> 1) * 32 + (qt & 1) * 2;
         f32x2 m[8];
 #pragma unroll
