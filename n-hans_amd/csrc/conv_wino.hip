@@ -48,7 +48,6 @@ constexpr int X_NSLOT = 152;                   // (row, tile) slots per plane: >
 constexpr int X_PLANE = X_NSLOT * 4 + 4;       // floats per plane (16 B = 8 channels of one half per slot)
 constexpr int X_VBUF = 16 * X_PLANE;           // floats per V buffer: 8 positions x {hi, lo}
 constexpr int X_RROWS = 21, X_RPX = 38;        // staged input tile of a chunk: rows (TR + KH - 1) x pixels (TJ*m + KH - 1)
-constexpr int X_RKIND = X_RROWS * X_RPX * 4;   // floats per piece kind (hi | lo): one 16-byte piece per (row, pixel)
 constexpr int X_NDMA = (2 * X_RROWS * X_RPX + 63) / 64;   // LDS-DMA wave-instructions per staged tile
 constexpr int X_DPW = (X_NDMA + XW - 1) / XW;  // ... per wave
 constexpr int X_RAW = X_NDMA * 256;            // floats per staged tile

@@ -58,8 +58,6 @@ __device__ __forceinline__ void wino_epilogue(const ConvArgs& a, const f32x16 (*
     const size_t fpix = (size_t)b * a.Ho * a.Wo;                              // uniform
     // position table = tt[ho] + ff[wo] (two small arrays: the [Ho*Wo, N] table of these layers, 1.8 MB, did not survive
     // in L2 and came from HBM again almost once per frame).  An absent table reads the zero page.
-    const int f_tf = a.tt ? 1 : 0;
-    const char* const ffb = reinterpret_cast<const char*>(a.tt ? a.ff : a.zero);
     const float lo_clamp = a.relu ? 0.f : -3.0e38f;
 
     // 0. the per-channel constants (ws, bias, idw of the block's 64 channels), fetched by the eight threads of
@@ -68,6 +66,32 @@ __device__ __forceinline__ void wino_epilogue(const ConvArgs& a, const f32x16 (*
     // cst: [ws | idw][64], then per block row r: bias + tt[r0 + r] (the time term of the position table rides in the bias
     // of the transform stage: v = fma(y, ws, bias + tt) + ff), fetched by the first tile-pixel of each row
     float* const cst = ct + 8 * 64 * W_LDM;
+    // ffl: the frequency term of the position table for the block's TJ*MO image columns and 64 channels, [column][64]
+    // floats in rows 20 .. of the constants area (rows 2 .. 19 hold the per-row biases: TR <= 18), staged ONCE per
+    // workgroup by LDS-DMA -- wave p the columns 4p .. 4p+3, wave 0 also 32 .. 35 -- and read from LDS by both passes'
+    // sweeps (round 5).  The table used to be 10 global loads per thread and pass: a third of the epilogue's vector-memory
+    // instructions, for 9 KB per workgroup that every image row reads again -- and what the epilogue is short of is
+    // vector-memory ISSUE.  A column outside the image, or an absent table (descriptor of size 0),
+    // stages zeros.  The request is asm: the compiler makes every LDS access it can see wait for a VISIBLE LDS-DMA of
+    // the same wave with vmcnt(0) -- which would make the accumulator dump wait for the residual requests as well.  It
+    // is the OLDEST request of the pass, so the counted wait in front of the constants' LDS stores covers it, and the
+    // barrier behind those publishes it.
+    float* const ffl = cst + (2 + 18) * 64;
+    static_assert((2 + 18) * 64 + 36 * 64 <= (2 + 64) * 64, "ffl inside the constants area");
+    if (first) {
+        const __amdgpu_buffer_rsrc_t frs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.tt ? a.ff : a.zero), 0,
+                                                                              a.tt ? a.Wo * a.N * 4 : 0, 0x00020000);
+        auto stage = [&](int c0) {
+            const int col = c0 + (lane >> 4), wo = j0 * MO + col;
+            const unsigned off = (col < TJ * MO && wo < a.Wo) ? (unsigned)((wo * a.N + nb * 64 + (lane & 15) * 4) * 4) : 0x80000000u;
+            const unsigned dst = (unsigned)(size_t)(__attribute__((address_space(3))) float*)(ffl + c0 * 64);   // LDS byte address (uniform)
+            unsigned keep;
+            asm volatile("s_mov_b32 %0, m0\n s_mov_b32 m0, %2\n s_nop 0\n buffer_load_dwordx4 %1, %3, 0 offen lds\n s_mov_b32 m0, %0"
+                         : "=&s"(keep) : "v"(off), "s"(__builtin_amdgcn_readfirstlane(dst)), "s"(frs) : "memory");
+        };
+        stage(p * 4);
+        if (p == 0) stage(32);
+    }
     if (kDev && es) es[3] = (long long)__builtin_amdgcn_s_memtime();
     // These eight requests are asm, and so is the wait for them further down: the compiler's count of what is in flight
     // does not survive the two branches, and left to it the wait in front of the LDS stores of the constants was
@@ -164,18 +188,8 @@ __device__ __forceinline__ void wino_epilogue(const ConvArgs& a, const f32x16 (*
     // 0 .. MO-1 the thread has just read (nobody else touches the slots of its tile-pixel and channels): the column loop
     // below then holds one column of outputs instead of MO, which is what lets the residual of all columns stay in
     // registers.  (Stored tensors carry 2^-e: ConvArgs::in_scale / id_scale / out_scale.)
-    // the position table (L2): the first TAHEAD columns ahead of the transform, then TAHEAD columns ahead of their use
-    // (all MO at once do not fit the register file beside the residuals)
-    const uint32_t to0 = ((uint32_t)(okq ? wo0 : 0) * (uint32_t)a.N + (uint32_t)n) * 4u * f_tf, tst = (uint32_t)a.N * 4u * f_tf;
-    f32x4 t0[MO], t1[MO];
-    auto table = [&](int i) {
-        const uint32_t o = to0 + (uint32_t)(i < lastc ? i : lastc) * tst;
-        t0[i] = *reinterpret_cast<const f32x4*>(ffb + o);
-        t1[i] = *reinterpret_cast<const f32x4*>(ffb + o + CHB * 4 * f_tf);
-    };
-    constexpr int TAHEAD = 2;
-#pragma unroll
-    for (int i = 0; i < TAHEAD; ++i) table(i);
+    // the position table's frequency term: from the workgroup's staged slice (ffl), column tt*MO + i of the block
+    const float* const ffc = ffl + ((rr < TR ? tt : 0) * MO) * 64 + c8 * CHA;
     __builtin_amdgcn_sched_barrier(0);
     float* const my = ct + q * W_LDM + c8 * 4;                                // + position * 64 * W_LDM + (0 | 32)
     static_assert(MO - RQ0 <= 4, "one late residual column per transform iteration");
@@ -226,7 +240,6 @@ __device__ __forceinline__ void wino_epilogue(const ConvArgs& a, const f32x16 (*
     int sat = 0;
 #pragma unroll
     for (int i = 0; i < MO; ++i) {
-        if (i + TAHEAD < MO) table(i + TAHEAD);
         const f32x4 ya = *reinterpret_cast<const f32x4*>(my + i * 64 * W_LDM);
         const f32x4 yb = *reinterpret_cast<const f32x4*>(my + i * 64 * W_LDM + 32);
         f32x4 i0 = {0.f, 0.f, 0.f, 0.f}, i1 = i0;
@@ -241,8 +254,9 @@ __device__ __forceinline__ void wino_epilogue(const ConvArgs& a, const f32x16 (*
             i0 = f32x4{rsv[i], rsv[i], rsv[i], rsv[i]};
             i1 = i0;
         }
-        const f32x4 r0v = fma4(iw0, i0, ya + t0[i]);           // (= epi_combine: ya already is fma(acc, ws, bias))
-        const f32x4 r1v = fma4(iw1, i1, yb + t1[i]);
+        const f32x4 t0 = *reinterpret_cast<const f32x4*>(ffc + i * 64), t1 = *reinterpret_cast<const f32x4*>(ffc + i * 64 + CHB);
+        const f32x4 r0v = fma4(iw0, i0, ya + t0);              // (= epi_combine: ya already is fma(acc, ws, bias))
+        const f32x4 r1v = fma4(iw1, i1, yb + t1);
         const bool valid = i < nvalid;
         float yc[8];
         bool over = false;
