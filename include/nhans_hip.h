@@ -124,7 +124,9 @@ void nhans_destroy(nhans_ctx* ctx);
  *           0: the direct kernels for every conv -- results agree to ~1e-5 on the logits),
  *          "winograd_f32_tensors" (1, default: with the Winograd form, the stack tensors that only Winograd launches read
  *           are stored f32 NHWC instead of split NHWC -- same size, same scaled values, less work in the transform;
- *           0: every tensor split -- results agree to ~1e-6 on the logits),
+ *           0: every tensor split -- results agree to ~1e-6 on the logits; 2: a TEST value -- f32 storage whatever the
+ *           readers are: a reader that is not a Winograd launch then refuses, the call returns NHANS_EHIP and nothing is
+ *           computed on a wrong layout),
  * (A `make DEV=1` build adds "debug_cycles_ptr" and the NHANS_ABLATE environment switch used by tools/; the default build has no developer hooks and reads no environment.)
  * Besides the workspace a context holds 64 MB of split-K scratch for the few launches that are
  * too small to fill the chip (the head's dense layer, the embedding tower at a few clips). */
