@@ -251,6 +251,9 @@ def test_bench_gpus_n_without_a_launcher_starts_n_ranks(lib_built):
     assert line["frames_per_s"] > 0 and line["status_flags"] == 0
     audio_per_step = 2 * 4 * (98 * 160 + 240) / 16000.0                  # both ranks' clips, trimmed to 98 frames
     assert abs(line["value"] * line["ms_per_step"] * 1e-3 - audio_per_step) < 1e-6 * audio_per_step
+    # every rank's own figures travel to rank 0 (round 5): the whole-job step time is the slowest rank's, barrier to barrier
+    pr = line["per_rank"]
+    assert [r["rank"] for r in pr] == [0, 1] and all(0 < r["ms_per_step"] <= line["ms_per_step"] * 1.001 for r in pr), pr
 
 
 def test_bench_eight_ranks_on_one_device_and_a_rank_that_dies(lib_built):
@@ -271,6 +274,7 @@ def test_bench_eight_ranks_on_one_device_and_a_rank_that_dies(lib_built):
     assert rc == 0, out
     line = json.loads([ln for ln in out.splitlines() if ln.startswith("{")][0])
     assert line["n_gpus"] == 8 and line["config"]["clips_per_gpu"] == 2 and line["status_flags"] == 0
+    assert [r["rank"] for r in line["per_rank"]] == list(range(8)) and all(r["ms_per_step"] > 0 for r in line["per_rank"])
     audio_per_step = 8 * 2 * (98 * 160 + 240) / 16000.0
     assert abs(line["value"] * line["ms_per_step"] * 1e-3 - audio_per_step) < 1e-6 * audio_per_step
     t0 = time.time()
