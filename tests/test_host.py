@@ -529,6 +529,50 @@ def test_winograd_kernel_isa_keeps_its_hand_counted_waits():
     assert "OK" in r.stdout
 
 
+def test_winograd_isa_checker_catches_what_it_is_there_for(tmp_path):
+    """tools/check_wino_isa.py is part of the build (Makefile: it checks the assembly of the object being linked).  A
+    checker that cannot fail is no check: three mutations of real kernel assembly -- a compiler-style copy INTO a weight
+    register between its request and the multiply block, a multiply block that opens with another wait count, one
+    residual request fewer than the epilogue's counted wait stands for -- must each fail it, the unmutated text pass."""
+    import subprocess
+    import sys
+    tool = os.path.join(ROOT, "tools", "check_wino_isa.py")
+    src = os.path.join(ROOT, "n-hans_amd", "csrc", ".isa", "conv_wino-hip-amdgcn-amd-amdhsa-gfx950.s")
+    if not os.path.exists(src):                       # (not built through the Makefile in this checkout: compile it)
+        src = str(tmp_path / "w.s")
+        subprocess.run([os.environ.get("HIPCC", "/opt/rocm/bin/hipcc"), "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "--cuda-device-only",
+                        "-fno-slp-vectorize", "-S", os.path.join(ROOT, "n-hans_amd", "csrc", "conv_wino.hip"), "-o", src], check=True)
+    text = open(src).read()
+
+    def check(t):
+        f = tmp_path / "m.s"
+        f.write_text(t)
+        return subprocess.run([sys.executable, tool, "--asm", str(f)], capture_output=True, text=True)
+    r = check(text)
+    assert r.returncode == 0, r.stdout
+    lines = text.split("\n")
+    # (a) the first weight-request asm block inside a K loop: a write to its first destination register right behind it
+    k = next(i for i, l in enumerate(lines) if "global_load_dwordx4" in l and "s[" in l and i > 300)
+    reg = re.search(r"global_load_dwordx4 v\[(\d+):", lines[k]).group(1)
+    end = next(i for i in range(k, k + 20) if "#ASMEND" in lines[i])
+    mut = lines[:end + 1] + ["\tv_mov_b32_e32 v%s, 0" % reg] + lines[end + 1:]
+    r = check("\n".join(mut))
+    assert r.returncode != 0 and "touches a weight register" in r.stdout, r.stdout[-400:]
+    # (b) a multiply block opening with vmcnt(5)
+    m = next(i for i, l in enumerate(lines) if "s_waitcnt vmcnt(4)" in l and "v_mfma" in "".join(lines[i:i + 12]))
+    mut = list(lines)
+    mut[m] = mut[m].replace("vmcnt(4)", "vmcnt(5)")
+    r = check("\n".join(mut))
+    assert r.returncode != 0 and "does not open with s_waitcnt vmcnt(4)" in r.stdout, r.stdout[-400:]
+    # (c) the epilogue: drop one residual request in front of a counted wait `s_waitcnt vmcnt(4)` that follows the constants
+    w = [i for i, l in enumerate(lines) if re.search(r"s_waitcnt vmcnt\(4\)\s*$", l) and "ASMSTART" in lines[i - 1] and "v_mfma" not in "".join(lines[i:i + 12])]
+    assert w, "no counted epilogue wait found"
+    j = next(i for i in range(w[0], w[0] - 200, -1) if re.match(r"\s*(global|buffer)_load_dwordx4", lines[i]) and "ASM" not in lines[i - 1])
+    mut = lines[:j] + lines[j + 1:]
+    r = check("\n".join(mut))
+    assert r.returncode != 0 and "vector-memory instructions between the constants" in r.stdout, r.stdout[-400:]
+
+
 def _wino_schedule_from_source():
     """What the queue model below needs, READ FROM conv_wino.hip instead of restated: the order of the request / wait /
     multiply / transform events of a period (the token sequence of the X_PERIOD macro), the immediates of the hand-written
