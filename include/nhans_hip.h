@@ -128,7 +128,7 @@ void nhans_destroy(nhans_ctx* ctx);
  *           readers are: a reader that is not a Winograd launch then refuses, the call returns NHANS_EHIP and nothing is
  *           computed on a wrong layout),
  * (A `make DEV=1` build adds "debug_cycles_ptr" and the NHANS_ABLATE environment switch used by tools/; the default build has no developer hooks and reads no environment.)
- * Besides the workspace a context holds 64 MB of split-K scratch for the few launches that are
+ * Besides the workspace a context holds 384 MB of split-K scratch for the few launches that are
  * too small to fill the chip (the head's dense layer, the embedding tower at a few clips). */
 int nhans_set_option(nhans_ctx* ctx, const char* key, int64_t value);
 

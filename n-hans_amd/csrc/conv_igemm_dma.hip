@@ -456,16 +456,23 @@ __global__ void __launch_bounds__(512) conv_igemm_dma(const ConvArgs a) {
                     const f32x4 v = {acc[t][j][4 * q], acc[t][j][4 * q + 1], acc[t][j][4 * q + 2], acc[t][j][4 * q + 3]};
                     *reinterpret_cast<f32x4*>(part + ((t * TN + j) * 4 + q) * 2048) = v;
                 }
-        __threadfence();
-        __syncthreads();
+        // One release per workgroup and an acquire in the last arriver only: an agent-scope fence writes the XCD's L2
+        // back AND invalidates it -- issued by all eight waves of every split (7,680 times in the head's dense launch)
+        // it kept emptying the L2 under the K loops of the workgroups still running
+        // (0.53 -> 0.25 ms for that launch, profiles/r05/ab_splitk_scratch_and_fences.txt).
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (explicit: a workgroup-scope barrier alone need not wait for stores)
+        __syncthreads();                                    // every wave's partial stores have reached this XCD's L2
         int* ticket = reinterpret_cast<int*>(smem);
-        if (tid == 0)
-            ticket[0] = __hip_atomic_fetch_add(a.kcounter + L, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        if (tid == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the write-back has completed before the ticket is taken
+            ticket[0] = __hip_atomic_fetch_add(a.kcounter + L, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         __syncthreads();
         const int old = ticket[0];
         __syncthreads();
         if (old != ksplit - 1) return;
-        __threadfence();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         if (tid == 0) a.kcounter[L] = 0;               // ready for the next launch on this stream
 #pragma unroll
         for (int t = 0; t < TM; ++t)

@@ -115,7 +115,9 @@ struct nhans_ctx {
     size_t ws_bytes = 0, ws_top = 0;
     // split-K scratch of the conv kernel (small launches only)
     float* kscratch = nullptr;
-    size_t kscratch_bytes = (size_t)64 << 20;
+    // (96 tiles x 32 groups x 128 KB: every launch the split-K rule of conv_igemm_dma.hip admits -- with 64 MB the head's
+    //  dense layer at the default 3,776 frame windows per pass, 30 tiles, ran unsplit on 30 of the 256 CUs)
+    size_t kscratch_bytes = (size_t)384 << 20;
     int* kcounter = nullptr;
     int kcounter_n = 1024;
     // Frame windows per pass of the stack.  Every launch runs whole "waves" of one workgroup per CU and all
