@@ -368,6 +368,9 @@ __global__ void __launch_bounds__(XW * 64) conv_wino(const ConvArgs a) {
     // c + 3.  In flight at the end of a period, in order: tile c+2 (4) | weights (8) | tile c+3 (4): vmcnt(12) says
     // tile c+2 has landed. ----
     long long dbg_t0 = 0, dbg_bar = 0, dbg_t1 = 0, dbg_mult = 0, dbg_xf = 0, dbg_wait = 0;
+    int dbg_pv = 0;                                // lane c: the low word of the time at the end of period c (v_writelane: no memory traffic in the loop)
+    long long dbg_rt0 = 0;
+    if constexpr (DBG) dbg_rt0 = (long long)__builtin_amdgcn_s_memrealtime();
     if constexpr (DBG) dbg_t0 = (long long)__builtin_amdgcn_s_memtime();
     int rb3 = 0;                                   // c % 3
 #define X_STAMP(ACCUM)                                                                             \
@@ -425,6 +428,7 @@ __global__ void __launch_bounds__(XW * 64) conv_wino(const ConvArgs a) {
         X_STAMP(dbg_wait)                                                                          \
         __builtin_amdgcn_s_barrier();                                                              \
         X_STAMP(dbg_bar)                                                                           \
+        if constexpr (DBG) { int keep_; asm volatile("s_mov_b32 %1, m0\n s_mov_b32 m0, %3\n s_nop 0\n v_writelane_b32 %0, %2, m0\n s_mov_b32 m0, %1" : "+v"(dbg_pv), "=&s"(keep_) : "s"(__builtin_amdgcn_readfirstlane((int)(tq_ - dbg_t0))), "s"(__builtin_amdgcn_readfirstlane(c_))); } \
         rb3 = rn_;                                                                                 \
     }
 #pragma unroll 1
@@ -480,10 +484,19 @@ __global__ void __launch_bounds__(XW * 64) conv_wino(const ConvArgs a) {
             e[0] = dbg_setup; e[1] = dbg_landed; e[2] = es[0] - dbg_t1; e[3] = es[1] - dbg_t1; e[4] = es[2] - dbg_t1; e[5] = dbg_mult; e[6] = dbg_xf; e[7] = dbg_wait;
             long long* f = a.dbg + (size_t)(6 << 20) + ((size_t)blockIdx.x * 12 + wave) * 4;   // transform: reads landed | arithmetic done (from its start) | entry -> first request
             f[0] = dbg_ts[0]; f[1] = dbg_ts[1]; f[2] = dbg_pre; f[3] = dbg_mid;
-            long long* h = a.dbg + (size_t)(8 << 20) + ((size_t)blockIdx.x * 12 + wave) * 16;  // epilogue, both passes, from the loop's end
-            for (int i = 0; i < 16; ++i) h[i] = es[i] ? es[i] - dbg_t1 : 0;
-            h[6] = t_end - dbg_t1;
+            if (blockIdx.x < 4096) {
+                // epilogue, both passes, from the loop's end (es[0..5], es[8..13]: conv_wino_common.h) | [16] drained | [17] 100 MHz ticks and
+                // [18] cycles from the K loop's start to here | [19] the launch's grid (every launch stamps the same buffer: the reader
+                // keeps the records of the LAST launch's grid only)
+                long long* h = a.dbg + (size_t)(8 << 20) + ((size_t)blockIdx.x * 12 + wave) * 24;
+                for (int i = 0; i < 16; ++i) h[i] = es[i] ? es[i] - dbg_t1 : 0;
+                h[16] = t_end - dbg_t1;
+                h[17] = (long long)__builtin_amdgcn_s_memrealtime() - dbg_rt0;
+                h[18] = t_end - dbg_t0;
+                h[19] = gridDim.x;
+            }
         }
+        if (a.dbg && lane < 32 && blockIdx.x < 4096) a.dbg[(size_t)(10 << 20) + ((size_t)blockIdx.x * 12 + wave) * 32 + lane] = dbg_pv;
     }
 }
 

@@ -132,13 +132,13 @@ __device__ __forceinline__ void wino_epilogue(const ConvArgs& a, const f32x16 (*
         if constexpr (IDM == 1) {
             const char* const idb = reinterpret_cast<const char*>(a.id + fpix * a.id_ld);
             const uint32_t o0 = (uint32_t)pix0 * (uint32_t)a.id_ld * 4u + (uint32_t)hoff * 2u, st = (uint32_t)a.id_ld * 4u;
-            const uint32_t o = (kDev && (a.wino_m >> 8 & 8)) ? (uint32_t)hoff * 2u : o0 + (uint32_t)(i < lastc ? i : lastc) * st;
+            const uint32_t o = (kDev && (a.wino_m >> 8 & 24)) ? (uint32_t)hoff * 2u : o0 + (uint32_t)(i < lastc ? i : lastc) * st;
             rh[i] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(idb + o));
             rl[i] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(idb + o + 64));
         } else if constexpr (IDM == 2) {
             const char* const idb = reinterpret_cast<const char*>(a.id + fpix * a.id_ld);
             const uint32_t o0 = ((uint32_t)pix0 * (uint32_t)a.id_ld + (uint32_t)n) * 4u, st = (uint32_t)a.id_ld * 4u;
-            const uint32_t o = o0 + (uint32_t)(i < lastc ? i : lastc) * st;
+            const uint32_t o = (kDev && (a.wino_m >> 8 & 24)) ? (uint32_t)n * 4u : o0 + (uint32_t)(i < lastc ? i : lastc) * st;   // (dev ablation 8 / 16: one L2-hot line)
             rh[i] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(idb + o));
             rl[i] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(idb + o + CHB * 4));
         } else if constexpr (IDM == 3) {

@@ -35,7 +35,10 @@ def main():
     g = spec.main_geometry()[block]
     raw = dbg.cpu().numpy()
     d = raw[:(4 << 20) // 48 * 48].reshape(-1, 12, 4).astype(np.float64)
-    nblk = int((d[:, 0, 0] > 0).sum())
+    # every Winograd launch of the call stamps the same buffer: the records beyond the LAST launch's grid belong to earlier,
+    # larger launches (until late in round 5 this tool averaged them in: its "block 3" figures were half block 1's)
+    nblk = int(raw[(8 << 20) + 19])
+    assert 0 < nblk <= int((d[:, 0, 0] > 0).sum())
     d = d[:nblk]
     m = d.mean(0)
     e = raw[(4 << 20):(4 << 20) + nblk * 96].reshape(nblk, 12, 8).astype(np.float64).mean(0)
@@ -52,11 +55,16 @@ def main():
               "tile wait %.0f, barrier %.0f | epilogue %.0f (pass 0: tiles in LDS %.0f, barrier %.0f, transformed %.0f)"
               % (w, f[w, 2], f[w, 3], e[w, 0], e[w, 1], m[w, 1], m[w, 0], m[w, 0] / nc, e[w, 5] / nc, e[w, 6] / nc, e[w, 7] / nc, m[w, 3] / nc, m[w, 2],
                  e[w, 2], e[w, 3], e[w, 4]))
-    h = raw[(8 << 20):(8 << 20) + nblk * 192].reshape(nblk, 12, 16).astype(np.float64).mean(0)
+    nb4 = min(nblk, 4096)                                                  # (the epilogue and per-period records: first 4,096 workgroups)
+    h = raw[(8 << 20):(8 << 20) + nb4 * 288].reshape(nb4, 12, 24).astype(np.float64).mean(0)
     for w in range(8):
         print("  wave %d epilogue from the loop's end: pass 0 entry %.0f, residual requested %.0f, tiles in LDS %.0f, barrier %.0f, transformed %.0f, columns stored %.0f | "
               "pass 1 entry %.0f, requested %.0f, tiles %.0f, barrier %.0f, transformed %.0f, stored %.0f | drained %.0f"
-              % (w, h[w, 3], h[w, 4], h[w, 0], h[w, 1], h[w, 2], h[w, 5], h[w, 11], h[w, 12], h[w, 8], h[w, 9], h[w, 10], h[w, 13], h[w, 6]))
+              % (w, h[w, 3], h[w, 4], h[w, 0], h[w, 1], h[w, 2], h[w, 5], h[w, 11], h[w, 12], h[w, 8], h[w, 9], h[w, 10], h[w, 13], h[w, 16]))
+    pv = raw[(10 << 20):(10 << 20) + nb4 * 384].reshape(nb4, 12, 32)[:, :, :nc].astype(np.float64)
+    per = np.diff(np.concatenate([np.zeros((nb4, 12, 1)), pv], axis=2), axis=2).mean(0)
+    print("  wave 0, cycles of each period (barrier to barrier):", " ".join("%.0f" % x for x in per[0]))
+    print("  s_memtime ticks per s_memrealtime tick (100 MHz) over loop + epilogue: %.2f (= the shader clock in MHz / 100)" % (h[0, 18] / max(h[0, 17], 1)))
 
 
 if __name__ == "__main__":
