@@ -531,9 +531,10 @@ def test_winograd_kernel_isa_keeps_its_hand_counted_waits():
 
 def test_winograd_isa_checker_catches_what_it_is_there_for(tmp_path):
     """tools/check_wino_isa.py is part of the build (Makefile: it checks the assembly of the object being linked).  A
-    checker that cannot fail is no check: three mutations of real kernel assembly -- a compiler-style copy INTO a weight
+    checker that cannot fail is no check: four mutations of real kernel assembly -- a compiler-style copy INTO a weight
     register between its request and the multiply block, a multiply block that opens with another wait count, one
-    residual request fewer than the epilogue's counted wait stands for -- must each fail it, the unmutated text pass."""
+    residual request fewer than the epilogue's counted wait stands for, a VALU write of a scalar address register right in front
+    of an asm request that reads it -- must each fail it, the unmutated text pass."""
     import subprocess
     import sys
     tool = os.path.join(ROOT, "tools", "check_wino_isa.py")
@@ -571,6 +572,13 @@ def test_winograd_isa_checker_catches_what_it_is_there_for(tmp_path):
     mut = lines[:j] + lines[j + 1:]
     r = check("\n".join(mut))
     assert r.returncode != 0 and "vector-memory instructions between the constants" in r.stdout, r.stdout[-400:]
+    # (d) a VALU write of the scalar base register right in front of a weight request inside asm (the wait states the compiler
+    # inserts for its own instructions are not inserted for the contents of inline asm)
+    sreg = re.search(r"global_load_dwordx4 v\[\d+:\d+\], v\d+, s\[(\d+):\d+\]", lines[k]).group(1)
+    start = next(i for i in range(k, k - 20, -1) if "#ASMSTART" in lines[i])
+    mut = lines[:start] + ["\tv_readfirstlane_b32 s%s, v0" % sreg] + lines[start:]
+    r = check("\n".join(mut))
+    assert r.returncode != 0 and "wait states earlier" in r.stdout, r.stdout[-400:]
 
 
 def _wino_schedule_from_source():

@@ -12,7 +12,11 @@ the file to gfx950 assembly and checks, for every instantiation of the kernel:
     read the registers it writes as weight operands, every multiply block's 32 weight registers are written by request
     blocks, and no instruction outside the request / multiply asm blocks mentions them in between;
   * the K loop contains no compiler-generated `s_waitcnt vmcnt` (all of them come from the source) and no LDS
-    instruction outside inline asm.
+    instruction outside inline asm;
+  * no vector-memory instruction INSIDE an asm block reads a scalar register (address pair, buffer descriptor) that a VALU
+    instruction wrote fewer than five instructions earlier: the compiler's hazard recognizer
+    inserts the wait states gfx9 needs there ("VALU writes SGPR -> VMEM reads that SGPR: 5") for its own instructions
+    only, not for the contents of inline asm (round 5).
 Exit code 0 = all good."""
 import os
 import re
@@ -32,6 +36,38 @@ def vgprs(text):
     for a in re.findall(r"\bv(\d+)\b", text):
         out.add(int(a))
     return out
+
+
+def sgprs(text):
+    out = set()
+    for a, b in re.findall(r"\bs\[(\d+):(\d+)\]", text):
+        out.update(range(int(a), int(b) + 1))
+    for a in re.findall(r"\bs(\d+)\b", text):
+        out.add(int(a))
+    if re.search(r"\bvcc\b", text):
+        out.update((106, 107))
+    return out
+
+
+def valu_sgpr_writes(code):
+    """scalar registers a VALU instruction writes: v_readfirstlane / v_readlane / e64 compares (first operand), the carry-out
+    of the 64-bit forms (second operand), vcc of the e32 compares and carry forms"""
+    t = code.strip()
+    if not t.startswith("v_"):
+        return set()
+    op, _, rest = t.partition(" ")
+    ops = [o.strip() for o in rest.split(",")]
+    w = set()
+    if op.startswith(("v_readfirstlane", "v_readlane")) or (op.startswith("v_cmp") and op.endswith("_e64")):
+        w |= sgprs(ops[0])
+    elif op.startswith("v_cmp"):
+        w |= {106, 107}
+    if op in ("v_mad_u64_u32", "v_mad_i64_i32") or (("_co_" in op or op.startswith("v_div_scale")) and op.endswith("_e64")):
+        if len(ops) > 1:
+            w |= sgprs(ops[1])
+    elif "_co_" in op:
+        w |= {106, 107}
+    return w
 
 
 def check_kernel(name, lines):
@@ -197,6 +233,28 @@ def check_kernel(name, lines):
             errs.append("line %d: compiler-visible LDS access inside the K loop: %s" % (i, l.strip()))
         if re.match(r"\s*scratch_", code):
             errs.append("line %d: scratch access inside the K loop: %s" % (i, l.strip()))
+    # asm-boundary hazard: VALU writes SGPR -> vector-memory instruction inside an asm block reads it (5 wait states)
+    code_lines = [(i, l.split(";")[0]) for i, l in enumerate(lines)]
+    code_lines = [(i, c) for i, c in code_lines if c.strip() and not c.strip().startswith((".", "#")) and not c.strip().endswith(":")]
+    inasm_at = set()
+    for b in blocks:
+        inasm_at.update(range(b[0], b[1] + 1))
+    for pos, (i, c) in enumerate(code_lines):
+        if i not in inasm_at or not re.match(r"\s*(global_|buffer_|flat_)", c):
+            continue
+        need = sgprs(c.split(None, 1)[1]) if len(c.split(None, 1)) > 1 else set()
+        back = code_lines[max(0, pos - 5):pos]
+        for d, (j, p) in enumerate(reversed(back)):
+            ws = 0
+            m = re.match(r"\s*s_nop (\d+)", p)
+            w = valu_sgpr_writes(p)
+            if w & need:
+                # wait states between the two: the instructions in between, an s_nop N counting N + 1
+                ws = sum((int(re.match(r"\s*s_nop (\d+)", q).group(1)) + 1) if re.match(r"\s*s_nop (\d+)", q) else 1
+                         for _, q in back[len(back) - d:])
+                if ws < 5:
+                    errs.append("line %d: %s reads a scalar register a VALU instruction wrote %d wait states earlier (line %d: %s)"
+                                % (i, c.strip()[:60], ws, j, p.strip()[:60]))
     return errs
 
 
