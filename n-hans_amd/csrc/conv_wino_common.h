@@ -101,12 +101,22 @@ __device__ __forceinline__ void wino_epilogue(const ConvArgs& a, const f32x16 (*
     f32x4 ka[4], kb[4];
     const bool row_head = tt == 0 && rr < TR;
     const bool chan_head = q == 0 && first;
+    // EVERY register such a request writes must be READ behind the wait: an output the compiler can prove unused is dead to it
+    // from the asm statement on, it puts other values there, and the load -- still in flight -- lands on them.  (Round 5:
+    // without a residual the idw pair was requested from the zero page and never read; variants of this epilogue whose
+    // register allocation put address arithmetic into those registers raised memory faults on some boxes of the pool.
+    // tools/check_wino_isa.py now checks the whole window from each request block to the wait.)
     if (chan_head) {
         const float* wsp = a.ws + n8;
-        const float* idp = IDM != 0 ? a.idw + n8 : a.zero;
-        asm volatile("global_load_dwordx4 %0, %4, off\n global_load_dwordx4 %1, %4, off offset:16\n"
-                     "global_load_dwordx4 %2, %5, off\n global_load_dwordx4 %3, %5, off offset:16"
-                     : "=&v"(ka[0]), "=&v"(ka[1]), "=&v"(ka[2]), "=&v"(ka[3]) : "v"(wsp), "v"(idp) : "memory");
+        if constexpr (IDM != 0) {
+            const float* idp = a.idw + n8;
+            asm volatile("global_load_dwordx4 %0, %4, off\n global_load_dwordx4 %1, %4, off offset:16\n"
+                         "global_load_dwordx4 %2, %5, off\n global_load_dwordx4 %3, %5, off offset:16"
+                         : "=&v"(ka[0]), "=&v"(ka[1]), "=&v"(ka[2]), "=&v"(ka[3]) : "v"(wsp), "v"(idp) : "memory");
+        } else {
+            asm volatile("global_load_dwordx4 %0, %2, off\n global_load_dwordx4 %1, %2, off offset:16"
+                         : "=&v"(ka[0]), "=&v"(ka[1]) : "v"(wsp) : "memory");
+        }
     }
     if (row_head) {
         const float* ttp = a.tt ? a.tt + (size_t)(ho < a.Ho ? ho : 0) * a.N + n8 : a.zero;

@@ -531,7 +531,7 @@ def test_winograd_kernel_isa_keeps_its_hand_counted_waits():
 
 def test_winograd_isa_checker_catches_what_it_is_there_for(tmp_path):
     """tools/check_wino_isa.py is part of the build (Makefile: it checks the assembly of the object being linked).  A
-    checker that cannot fail is no check: four mutations of real kernel assembly -- a compiler-style copy INTO a weight
+    checker that cannot fail is no check: five mutations of real kernel assembly -- a compiler-style copy INTO a weight
     register between its request and the multiply block, a multiply block that opens with another wait count, one
     residual request fewer than the epilogue's counted wait stands for, a VALU write of a scalar address register right in front
     of an asm request that reads it -- must each fail it, the unmutated text pass."""
@@ -579,6 +579,15 @@ def test_winograd_isa_checker_catches_what_it_is_there_for(tmp_path):
     mut = lines[:start] + ["\tv_readfirstlane_b32 s%s, v0" % sreg] + lines[start:]
     r = check("\n".join(mut))
     assert r.returncode != 0 and "wait states earlier" in r.stdout, r.stdout[-400:]
+    # (e) a write into a register of the epilogue's FIRST constants request, right behind that request (far in front of the
+    # counted wait, with the second request block in between): what the compiler does with a requested register the source
+    # never reads -- the latent fault round 5 found in variants of the epilogue
+    c0 = next(i for i, l in enumerate(lines) if re.search(r"global_load_dwordx4 v\[\d+:\d+\], v\[\d+:\d+\], off\s*$", l.split(";")[0]) and "ASMSTART" in lines[i - 1])
+    creg = re.search(r"global_load_dwordx4 v\[(\d+):", lines[c0]).group(1)
+    cend = next(i for i in range(c0, c0 + 8) if "#ASMEND" in lines[i])
+    mut = lines[:cend + 1] + ["\tv_mov_b32_e32 v%s, 0" % creg] + lines[cend + 1:]
+    r = check("\n".join(mut))
+    assert r.returncode != 0 and "is touched before the wait" in r.stdout, r.stdout[-400:]
 
 
 def _wino_schedule_from_source():

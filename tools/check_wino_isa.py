@@ -193,32 +193,43 @@ def check_kernel(name, lines):
     # the epilogue's constants: asm requests (64-bit address, "off"), then compiler-visible residual requests, then the
     # hand-written s_waitcnt vmcnt(N): exactly N vector-memory instructions lie between the last constants block and
     # the wait, and nothing in between mentions the constants' registers
-    consts = [b for b in blocks if b[2] and sum("global_load_dwordx4" in l and l.split(";")[0].rstrip().endswith(("off", "offset:16")) for l in b[2]) == 4]
+    def is_const_block(b):
+        ld = [l.split(";")[0].rstrip() for l in b[2] if "global_load_dwordx4" in l]
+        return len(ld) in (2, 4) and len(ld) == len([l for l in b[2] if l.strip()]) and all(l.endswith(("off", "offset:16")) for l in ld)
+    consts = [b for b in blocks if is_const_block(b)]
     waits = [b for b in blocks if len([l for l in b[2] if l.strip()]) == 1 and re.search(r"s_waitcnt vmcnt\(\d+\)\s*$", b[2][0])]
     if len(consts) < 2:
         errs.append("epilogue: constants request blocks not found")
     for w in waits:
         if w[0] < back[1]:
             continue                                          # (the loop's own waits)
-        prev = [c for c in consts if c[1] < w[0]]
-        if not prev or w[0] - prev[-1][1] > 400:
+        prev = [c for c in consts if c[1] < w[0] and w[0] - c[1] <= 600]
+        # (only the blocks of THIS pass: those behind the previous epilogue wait)
+        before = [x for x in waits if back[1] < x[0] < w[0]]
+        if before:
+            prev = [c for c in prev if c[0] > before[-1][1]]
+        if not prev:
             continue
         n = int(re.search(r"vmcnt\((\d+)\)", w[2][0]).group(1))
-        regs = set()
-        for c in prev[-2:]:
-            if w[0] - c[1] <= 400:
-                regs |= load_regs(c)
-        cnt, bad = 0, []
+        # exactly n vector-memory instructions lie between the LAST constants block and the wait ...
+        cnt = 0
         for i in range(prev[-1][1] + 1, w[0]):
             code = lines[i].split(";")[0]
             if re.match(r"\s*(global_|buffer_|scratch_|flat_)", code):
                 cnt += 1
-            if vgprs(code) & regs:
-                bad.append(lines[i].strip())
         if cnt < n or (cnt != n and not dbg):
             errs.append("epilogue: %d vector-memory instructions between the constants and s_waitcnt vmcnt(%d) (line %d)" % (cnt, n, w[0]))
-        for t in bad:
-            errs.append("epilogue: a constants register is touched before the wait: " + t)
+        # ... and from EACH constants block to the wait nothing mentions the registers that block writes -- neither the
+        # compiler's own instructions nor a later request block (two loads in flight into one register).  A register whose
+        # value the source never reads is free to the compiler from the asm statement on: round 5's faults.
+        for c in prev:
+            regs = load_regs(c)
+            for i in range(c[1] + 1, w[0]):
+                code = lines[i].split(";")[0]
+                if vgprs(code) & regs:
+                    errs.append("epilogue: a register of the constants request at line %d is touched before the wait (line %d): %s"
+                                % (c[0], i, lines[i].strip()[:80]))
+                    break
     inasm = False
     for i in range(first, back[1] + 1):
         l = lines[i]
