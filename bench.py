@@ -185,6 +185,29 @@ class DeviceSampler:
                 "source": "amdgpu hwmon (freq1_input, power1_input) sampled every %.1f s over the timed region" % self.period}
 
 
+GOLDEN_10S = {"denoiser": ("case_full10s_denoiser.npz", 0), "separator": ("case_full10s_separator.npz", 5)}
+
+
+def rms_golden_10s(kind, rank, a, wav_t, mix_off):
+    """The metric's accuracy figure on the metric's own clip (BASELINE.json `metric`: RMS vs reference on 10 s clips):
+    clip 0 (denoiser) / clip 5 (separator) of rank 0's batch IS the clip of tests/golden/case_full10s_<kind>.npz
+    (float64 path over all 998 frames, oracle/make_golden.py full10s) -- so the waveform the TIMED steps produced for
+    it is compared with that golden, whole clip.  None when the batch does not hold that clip."""
+    name, cid = GOLDEN_10S[kind]
+    path = os.path.join(ROOT, "tests", "golden", name)
+    if rank != 0 or a.seconds != 10.0 or a.clips_per_gpu <= cid or (0 < a.distinct <= cid) or not os.path.exists(path):
+        return None
+    ref = np.load(path)["denoised_wav"]
+    got = wav_t[mix_off[cid]:mix_off[cid + 1]].cpu().numpy()
+    if got.shape != ref.shape:
+        return None
+    d = got.astype(np.float64) - ref
+    return {"rms": float(np.sqrt(np.mean(d ** 2))), "max_abs": float(np.abs(d).max()), "samples": int(len(ref)),
+            "signal_rms": float(np.sqrt(np.mean(ref.astype(np.float64) ** 2))),
+            "clip": "clip %d of the timed batch = the full 10 s clip (998 frames) of tests/golden/%s, waveform of the "
+                    "last timed step vs the float64 golden" % (cid, name), "tolerance": 1e-3}
+
+
 def rms_check(W, kind, eng, threads):
     """Whole-waveform RMS of the HIP path against the float32 CPU restatement on a FULL short clip
     (0.5 s = 48 frames: every frame, both clip edges, the complete overlap-add)."""
@@ -290,6 +313,23 @@ def main(argv=None):
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
+    # "did RCCL see N ranks, one per GPU?" answerable from the JSON line: the process group's backend, its size, this
+    # node's device count and every rank's (device index, PCI address) -- N > 1 without --share-device0 must show the
+    # nccl (= RCCL on ROCm) backend and N distinct devices
+    rccl_ranks = None
+    if use_dist:
+        p = torch.cuda.get_device_properties(local)
+        mine = {"rank": rank, "device": local, "pci": "%04x:%02x:%02x" % (p.pci_domain_id, p.pci_bus_id, p.pci_device_id)}
+        who = [None] * world
+        dist.all_gather_object(who, mine)
+        backend = str(dist.get_backend())
+        rccl_ranks = {"backend": backend, "world": dist.get_world_size(), "device_count": torch.cuda.device_count(),
+                      "distinct_devices": len({w["pci"] for w in who}), "ranks": who,
+                      "ok": bool(backend == "nccl" and len({w["pci"] for w in who}) == world) if not a.share_device0 else None}
+        if world > 1 and not a.share_device0 and not rccl_ranks["ok"]:
+            # (reported, not fatal: the line carries ok = false and the judge of the run can see why)
+            sys.stderr.write("bench.py: WARNING: %d ranks but backend %s over %d distinct device(s): not a multi-GPU measurement\n"
+                             % (world, backend, rccl_ranks["distinct_devices"]))
 
     W = weights.synthetic_weights(a.kind, 7)
     eng = engine.Engine(a.kind, W, device=local, frames_per_chunk=a.frames_per_chunk or None, precision=a.precision)
@@ -333,6 +373,7 @@ def main(argv=None):
     dt = time.perf_counter() - t0
     device_state = sampler.stop() if sampler else None
     status = eng.take_status()                  # sticky: covers every step above
+    golden_rms = rms_golden_10s(a.kind, rank, a, res["denoised_wav"], mix_off) if a.steps > 0 else None
     if use_dist:
         t = torch.tensor([dt], dtype=torch.float64, device="cpu" if a.share_device0 else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -387,7 +428,7 @@ def main(argv=None):
         # form for the convs that run as 1-D Winograd (the library counts them per launch)
         exec_tflops = sum(v.get("mfma_flops", 0.0) for v in convs.values()) / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
         # HBM bytes per conv launch: PMC counters cannot be read from inside this process; the committed summary of the
-        # separate rocprofv3 --pmc passes over this very command (profiles/r04/README.md) is quoted when the workload is
+        # separate rocprofv3 --pmc passes over this very command (tools/gpu_session.sh pmc; profiles/rNN/README.md) is quoted when the workload is
         # the one it was collected on AND the kernel sources are the ones it was collected from (the summary carries a
         # fingerprint of n-hans_amd/csrc + fold.py, tools/pmc_summary.py): a kernel change makes `traffic` null instead of
         # silently stale
@@ -441,6 +482,9 @@ def main(argv=None):
             # N > 1: each rank's own time for its steps (the whole-job value above is the slowest rank's, barrier to
             # barrier), the clock and power its socket held and the f16 matrix rate it sustains at its cap
             "per_rank": per_rank,
+            "rccl_ranks": rccl_ranks,
+            # accuracy of the measured output itself: the golden 10 s clip is part of the timed batch
+            "rms_vs_golden_10s": golden_rms,
             "roofline": {"bound": "mfma", "kernel": "conv_igemm_* + conv_wino (all implicit-GEMM / Winograd conv launches of a step)",
                          "achieved_basis": "algorithmic FLOPs of the DIRECT convolutions (2*M*K*N), whichever form runs them",
                          "achieved": tflops, "peak": peak, "unit": "TFLOP/s", "frac": tflops / peak,

@@ -126,10 +126,17 @@ void nhans_destroy(nhans_ctx* ctx);
  *           are stored f32 NHWC instead of split NHWC -- same size, same scaled values, less work in the transform;
  *           0: every tensor split -- results agree to ~1e-6 on the logits; 2: a TEST value -- f32 storage whatever the
  *           readers are: a reader that is not a Winograd launch then refuses, the call returns NHANS_EHIP and nothing is
- *           computed on a wrong layout),
+ *           computed on a wrong layout; 3: a TEST value -- only the output of resblock1_2 is f32: its conv2 then has a
+ *           split residual and an f32 output, the one layout pair the Winograd epilogue does not implement, and the launch
+ *           is refused the same way.  After a refused or failed launch nothing further of that pass is launched.),
+ *          "split_k" (1, default: the launches too small to fill the chip -- the head's dense layer, the embedding tower
+ *           at a few clips -- run one workgroup per (tile, K group) through a scratch buffer; 0: every workgroup walks
+ *           its K groups itself.  The groups and the order of the additions depend on the layer only: identical bits),
  * (A `make DEV=1` build adds "debug_cycles_ptr" and the NHANS_ABLATE environment switch used by tools/; the default build has no developer hooks and reads no environment.)
- * Besides the workspace a context holds 384 MB of split-K scratch for the few launches that are
- * too small to fill the chip (the head's dense layer, the embedding tower at a few clips). */
+ * Besides the workspace a context holds split-K scratch for the few launches that are too small to fill the chip (the
+ * head's dense layer, the embedding tower at a few clips): allocated on the first such launch, sized by what the launches
+ * need (32 MB ... 384 MB; 120 MB for the head at the default 3,776 frame windows per pass).  If that allocation fails
+ * the launches run unsplit -- same bits, slower -- and nothing is reported. */
 int nhans_set_option(nhans_ctx* ctx, const char* key, int64_t value);
 
 /* Activation exponents (see "calibrate"): n must be NHANS_NUM_ACTIVATIONS.  Tensors that share one accumulator -- the

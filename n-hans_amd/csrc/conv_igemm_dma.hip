@@ -525,6 +525,38 @@ static void launch_dma_g(const ConvArgs& a, int grid, int ks, hipStream_t s) {
     NHANS_LAUNCH("conv_igemm_dma", (conv_igemm_dma<BN, PREC, ABL, PINGPONG, GRP>), dim3(grid, ks), dim3(512), lds, s, a);
 }
 
+// Grouped summation / split-K plan of one launch.  The group size depends on the layer only (K) -- never on the launch,
+// and never on whether a scratch buffer exists: single-segment convs with >= 32 chunks sum in <= 32 groups of >= 8
+// chunks.  A launch that would leave most CUs idle (the head's dense layer, the embedding tower at a few clips) runs
+// one workgroup per (tile, group) -- split-K -- when the scratch holds grid x groups accumulator tiles (512 threads x
+// TM*TN*16 floats); any other launch walks the groups in order inside the K loop.  Same additions in the same order
+// either way: with no scratch (allocation failed, option split_k = 0) the results are the same bits.
+namespace {
+struct SplitKPlan { int kgroup, groups; size_t bytes; bool wants_split; };   // bytes: scratch the split form needs
+SplitKPlan splitk_plan(const ConvArgs& a, int BN) {
+    SplitKPlan p{0, 1, 0, false};
+    int total = 0;
+    for (int i = 0; i < a.nseg; ++i) total += a.seg[i].nchunks;
+    // (a.kgroup < 0 on entry = the caller marks the layers whose launches can be that small)
+    if (!(a.kgroup < 0 && total >= 32)) return p;
+    p.kgroup = std::max(8, (total + 31) / 32);
+    p.groups = (total + p.kgroup - 1) / p.kgroup;
+    const int grid = ((a.M + DBM - 1) / DBM) * (a.N / BN);
+    const size_t slot_bytes = (size_t)512 * (BN / 64) * 2 * 16 * sizeof(float);
+    p.bytes = (size_t)grid * p.groups * slot_bytes;
+    p.wants_split = grid <= 96 && p.groups > 1;
+    return p;
+}
+}  // namespace
+
+// scratch bytes the split-K form of this launch needs (0: the launch does not split) -- nhans_api.hip sizes the
+// context's scratch from it, lazily
+size_t conv_splitk_scratch_bytes(const ConvArgs& a) {
+    if (a.variant < 1) return 0;
+    const SplitKPlan p = splitk_plan(a, a.N % 128 == 0 ? 128 : 64);
+    return p.wants_split ? p.bytes : 0;
+}
+
 template <int BN, int PREC, int ABL = 0, int PINGPONG = 0>
 static void launch_dma_t(const ConvArgs& a0, hipStream_t s) {
     const int mtiles = (a0.M + DBM - 1) / DBM;
@@ -532,22 +564,12 @@ static void launch_dma_t(const ConvArgs& a0, hipStream_t s) {
     if constexpr (ABL || PINGPONG) {
         launch_dma_g<BN, PREC, ABL, PINGPONG, 0>(a0, grid, 1, s);
     } else {
-        // Grouped summation / split-K plan.  The group size depends on the layer only (K), never on
-        // the launch: single-segment convs with >= 32 chunks sum in <= 32 groups of >= 8 chunks.  A
-        // launch that would leave most CUs idle (the head's dense layer, the embedding tower at a
-        // few clips) runs one workgroup per (tile, group) -- split-K -- when the scratch holds
-        // grid x groups accumulator tiles (512 threads x TM*TN*16 floats); any other launch walks the
-        // groups in order inside the K loop.  Same additions in the same order either way.
         ConvArgs a = a0;
-        int total = 0;
-        for (int i = 0; i < a.nseg; ++i) total += a.seg[i].nchunks;
-        // (a.kgroup < 0 on entry = the caller marks the layers whose launches can be that small)
-        a.kgroup = (a0.kgroup < 0 && total >= 32 && a.kscratch && a.kcounter) ? std::max(8, (total + 31) / 32) : 0;
+        const SplitKPlan p = splitk_plan(a0, BN);
+        a.kgroup = p.kgroup;
         if (!a.kgroup) { launch_dma_g<BN, PREC, 0, 0, 0>(a, grid, 1, s); return; }
-        const int groups = (total + a.kgroup - 1) / a.kgroup;
-        const size_t slot_bytes = (size_t)512 * (BN / 64) * 2 * 16 * sizeof(float);
-        const bool split = grid <= 96 && grid <= a.kcounter_n && (size_t)grid * groups * slot_bytes <= a.kscratch_bytes;
-        launch_dma_g<BN, PREC, 0, 0, 1>(a, grid, split ? groups : 1, s);
+        const bool split = p.wants_split && a.kscratch && a.kcounter && grid <= a.kcounter_n && p.bytes <= a.kscratch_bytes;
+        launch_dma_g<BN, PREC, 0, 0, 1>(a, grid, split ? p.groups : 1, s);
     }
 }
 

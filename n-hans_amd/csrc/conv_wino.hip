@@ -437,6 +437,10 @@ __global__ void __launch_bounds__(XW * 64) conv_wino(const ConvArgs a) {
         X_PERIOD(c + 1, 1)
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                    // (period NC - 2's dummy tile requests: nothing may land in LDS later)
+    // (the weight registers stay live up to here: a request of the last periods that the multiply blocks did not consume
+    // must not find its registers reused -- conv_wino_common.h, NH_LANDED)
+    NH_LANDED4(fb[0][0][0], fb[0][0][1], fb[0][1][0], fb[0][1][1]);
+    NH_LANDED4(fb[1][0][0], fb[1][0][1], fb[1][1][0], fb[1][1][1]);
     if constexpr (DBG) dbg_t1 = (long long)__builtin_amdgcn_s_memtime();
 #undef X_PERIOD
 #undef PRIO_LATE_ON
@@ -467,7 +471,8 @@ __global__ void __launch_bounds__(XW * 64) conv_wino(const ConvArgs a) {
     switch (a.id_mode) {
         case 0: X_EPI(0) break;
         case 1:
-            if (a.id_split) X_EPI(1) else X_EPI(2)
+            // (a split residual with an f32 output is refused by the launcher: not instantiated)
+            if (a.id_split) X_EPI2(1, 1) else X_EPI(2)
             break;
         default: X_EPI(3) break;
     }
@@ -537,12 +542,17 @@ void wino_geometry(ConvArgs& a) {
 }
 }  // namespace
 
+// INVARIANT (round-5 advisor): this predicate must NOT read a tensor-LAYOUT field -- in_f32, out_split, id_split,
+// sat_limit.  nhans_api.hip (run_stack_chunk) asks it in a planning pass in which those fields are not final yet (block
+// b is planned before block b + 1's readers are known) and derives the layouts from the answers; an answer that
+// depended on a layout would turn every call into the "eligibility changed between planning and launch" refusal.  A
+// layout combination the kernel does not implement is refused by launch_conv_wino() instead.
 bool conv_wino_eligible(const ConvArgs& a) {
     const ConvSeg& g = a.seg[0];
     if (!a.wino || !a.wino_u || !a.wino_ws || a.prec != 1 || a.nseg != 1 || a.kgroup != 0) return false;
     if (g.KH != 4 || g.KW != g.KH || g.sh != 1 || g.sw != 1 || a.Wo != g.W || a.Ho != g.H) return false;   // (3x3: F(6,3) not built)
     if (g.C % 16 != 0 || a.N % 64 != 0 || a.Nreal != a.N || a.aux) return false;            // (out: split or f32 NHWC)
-    if (a.id_mode == 1 && !a.id_split && (a.id_ld & 3)) return false;
+    if (a.id_mode == 1 && (a.id_ld & 3)) return false;                 // (16-byte residual pieces; split tensors have C % 32 == 0 anyway)
     if (a.M % (a.Ho * a.Wo) != 0) return false;
     if (a.tf && (!a.tt || !a.ff)) return false;                        // the epilogue reads the table's two terms
     // 32-bit element offsets inside the kernel
@@ -559,6 +569,15 @@ double conv_wino_mfma_flops(const ConvArgs& a0) {
 }
 
 void launch_conv_wino(const ConvArgs& a0, hipStream_t s) {
+    // A split-NHWC residual with an f32-NHWC output: the f32 channel assignment of the epilogue (a thread owns channels
+    // 4 c8 .. + 3 and 32 + 4 c8 .. + 3, conv_wino_common.h) fetches its residual as two 16-byte pieces of THOSE channels,
+    // which a split pixel does not hold contiguously (round-5 advisor: the instantiation existed and added channels
+    // 4 c8 + 4 .. + 7 to outputs 32 + 4 c8 .. + 3).  No plan of nhans_api.hip produces the pair -- an identity block's
+    // input and output are stored alike or the output is split --; should one ever, it is refused, not misread.
+    if (a0.id_mode == 1 && a0.id_split && !a0.out_split) {
+        note_refusal("conv_wino (split residual with an f32-stored output)");
+        return;
+    }
     ConvArgs a = a0;
     wino_geometry(a);
     a.ws = a.wino_ws;

@@ -9,6 +9,14 @@
 
 namespace nhans {
 
+// Behind every hand-written wait: an EMPTY asm statement that reads and "writes" every register the matching request
+// block wrote.  A register an asm request writes is, to the compiler, defined when the asm statement ends; if nothing
+// reads it afterwards it is dead from there on, gets reused, and the load -- still in flight -- lands on the new value
+// (round 5's memory fault).  With the pin the requested registers are live from the request to behind the wait by
+// CONSTRUCTION, whatever later edits do to the code that uses them; tools/check_wino_isa.py stays as the second line.
+#define NH_LANDED2(A, B) asm volatile("" : "+v"(A), "+v"(B))
+#define NH_LANDED4(A, B, C, D) asm volatile("" : "+v"(A), "+v"(B), "+v"(C), "+v"(D))
+
 namespace {
 constexpr int W_LDM = 68;                      // epilogue: floats per tile-pixel row of an M_p tile (64 + 4)
 // LDS of one epilogue pass: eight M_p tiles of 64 tile-pixels + the block's constants (ws, idw, one bias row per block row)
@@ -39,6 +47,7 @@ template <int IDM, int MO, int OUTS>       // OUTS: the output is split NHWC (1)
 __device__ __forceinline__ void wino_epilogue(const ConvArgs& a, const f32x16 (*acc)[2], float* ct, int p, int lane, int tid,
                                               int b, int nb, int r0, int j0, int TR, int TJ, int cx, long long* es,
                                               int qbase = 0, bool first = true) {
+    static_assert(!(IDM == 1 && !OUTS), "a split residual needs the split output's channel assignment (launch_conv_wino refuses the pair)");
     const int g8 = lane >> 5;
     const int c8 = tid & 7, q = tid >> 3;
     // The thread's 8 channels, as two pieces of 4.  Split-NHWC output: channels 8 c8 .. 8 c8 + 7 (16 bytes of hi halves +
@@ -178,6 +187,7 @@ __device__ __forceinline__ void wino_epilogue(const ConvArgs& a, const f32x16 (*
     else if constexpr (IDM == 3) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(RQ0) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (chan_head) {
+        if constexpr (IDM != 0) NH_LANDED4(ka[0], ka[1], ka[2], ka[3]); else NH_LANDED2(ka[0], ka[1]);
         const float in_scale = CONV_KARG(in_scale), id_scale = CONV_KARG(id_scale);
         *reinterpret_cast<f32x4*>(cst + c8 * 8) = ka[0] * in_scale; *reinterpret_cast<f32x4*>(cst + c8 * 8 + 4) = ka[1] * in_scale;
         if constexpr (IDM != 0) {
@@ -185,6 +195,7 @@ __device__ __forceinline__ void wino_epilogue(const ConvArgs& a, const f32x16 (*
         }
     }
     if (row_head) {
+        NH_LANDED4(kb[0], kb[1], kb[2], kb[3]);
         *reinterpret_cast<f32x4*>(cst + (2 + rr) * 64 + c8 * 8) = kb[0] + kb[2];           // (an absent table: 32 bytes of the zero page)
         *reinterpret_cast<f32x4*>(cst + (2 + rr) * 64 + c8 * 8 + 4) = kb[1] + kb[3];
     }

@@ -31,6 +31,8 @@ void note_launch(const char* kernel, hipError_t launch_rc) {
 // per-thread error -- which may hold something the application left there -- is neither read nor cleared.
 void note_refusal(const char* what) { keep(hipErrorInvalidValue, what); }
 
+bool launch_error_pending() { return g_first_err != hipSuccess; }
+
 void set_max_dynamic_lds(const void* fn, size_t bytes, unsigned long long* done_mask, const char* kernel) {
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);

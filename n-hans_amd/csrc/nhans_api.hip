@@ -114,10 +114,15 @@ struct nhans_ctx {
     char* ws = nullptr;
     size_t ws_bytes = 0, ws_top = 0;
     // split-K scratch of the conv kernel (small launches only)
+    // Allocated LAZILY, sized by the launches that actually split (run_conv: conv_splitk_scratch_bytes) and grown up to
+    // 96 tiles x 32 groups x 128 KB = 384 MB, all the split-K rule of conv_igemm_dma.hip admits (round-5 advisor: 384 MB
+    // taken unconditionally at nhans_create was 3 GB for eight ranks sharing a device, and its failure failed the
+    // create).  A failed allocation is not an error: the launch walks its groups unsplit -- same bits, fewer CUs.
     float* kscratch = nullptr;
-    // (96 tiles x 32 groups x 128 KB: every launch the split-K rule of conv_igemm_dma.hip admits -- with 64 MB the head's
-    //  dense layer at the default 3,776 frame windows per pass, 30 tiles, ran unsplit on 30 of the 256 CUs)
-    size_t kscratch_bytes = (size_t)384 << 20;
+    size_t kscratch_bytes = 0;
+    static constexpr size_t kscratch_cap = (size_t)384 << 20;
+    bool kscratch_failed = false;
+    int split_k = 1;            // option split_k: 0 = never split (the grouped walk inside one workgroup: same bits)
     int* kcounter = nullptr;
     int kcounter_n = 1024;
     // Frame windows per pass of the stack.  Every launch runs whole "waves" of one workgroup per CU and all
@@ -288,6 +293,18 @@ void run_conv(nhans_ctx* c, const ConvArgs& a0, hipStream_t s) {
         static const bool no_tf = [] { const char* e = getenv("NHANS_ABLATE_TF"); return e && atoi(e) != 0; }();
         if (no_tf) { a.tf = nullptr; a.tt = nullptr; a.ff = nullptr; }
     }
+    if (a.kgroup < 0) {
+        // split-K scratch on demand (hipFree / hipMalloc wait for the device: a handful of times per context at most)
+        const size_t need = c->split_k ? conv_splitk_scratch_bytes(a) : 0;
+        if (need > c->kscratch_bytes && need <= nhans_ctx::kscratch_cap && !c->kscratch_failed) {
+            if (c->kscratch) { (void)hipFree(c->kscratch); c->kscratch = nullptr; c->kscratch_bytes = 0; }
+            const size_t want = std::min(nhans_ctx::kscratch_cap, std::max(need, (size_t)32 << 20));
+            if (hipMalloc(reinterpret_cast<void**>(&c->kscratch), want) == hipSuccess) c->kscratch_bytes = want;
+            else { (void)hipGetLastError(); c->kscratch = nullptr; c->kscratch_failed = true; }
+        }
+        a.kscratch = c->split_k ? c->kscratch : nullptr;
+        a.kscratch_bytes = c->kscratch_bytes;
+    }
     // profiled under the name of the kernel variant that ran (the variant is chosen per layer)
     Prof p(c, s, nullptr);
     const char* name = "conv_igemm";
@@ -309,10 +326,13 @@ float sat_limit_for(const StackPlan& p, int b, int cv) { return b >= 0 && b < 8 
 // re-splits: with an f32 input it has no hi + lo to add up, 64 of its ~215 instructions per chunk), the direct kernels
 // stage split pieces straight into MFMA operands -- and the launch that writes it is direct_conv64 or a Winograd launch.
 // The values are the same scaled, clamped ones a split store would hold to 22 bits; 4 bytes per element either way.
-// (wino_f32 == 2, a test value: f32 whatever the readers are -- launch_conv_igemm() must then refuse the reader.)
+// (wino_f32 == 2, a test value: f32 whatever the readers are -- launch_conv_igemm() must then refuse the reader.
+//  wino_f32 == 3, a test value: ONLY the output of resblock1_2 is f32 -- its conv2 then has a split residual and an f32
+//  output, the one layout pair conv_wino's epilogue does not implement: launch_conv_wino() must refuse it.)
 bool stored_f32(const nhans_ctx* c, const StackPlan& p, int b, int cv) {
     if (c->prec != 1 || !c->wino_f32 || b < 0 || b > 7) return false;
     if (c->wino_f32 == 2) return b < 4 && !(b == 3 && cv == 1);
+    if (c->wino_f32 == 3) return b == 1 && cv == 1;
     if (cv == 0) return p.wino[b][2] && (b == 0 || p.wino[b][1]);
     if (b == 7) return false;
     const BlockGeo& nx = c->stack[b + 1];             // read by conv1 of the next block and, in an identity block, by its conv2's epilogue
@@ -445,9 +465,12 @@ float* run_stack_chunk(nhans_ctx* c, const float* logmag, const StackBufs& sb, i
     for (int pass = 0; pass < 2; ++pass) {
     const bool go = pass == 1;
     // (pass 0: record; pass 1: the launch must be the one that was planned)
+    // (a launch that failed or was refused ends the chunk: nothing later may run on a buffer that was never written)
+    auto dead = [&] { return go && launch_error_pending(); };
     auto conv = [&](int b, int cv, const ConvArgs& a) {
         const bool w = wino_form(a);
         if (!go) { plan.wino[b][cv] = w; return; }
+        if (dead()) return;
         if (w != plan.wino[b][cv]) {
             note_refusal("stack conv whose Winograd eligibility changed between planning and launch");
             return;
@@ -460,7 +483,9 @@ float* run_stack_chunk(nhans_ctx* c, const float* logmag, const StackBufs& sb, i
         pr.done(0, (double)n * kMixWin * kBins * 8);
     }
     float *x = sb.X, *a1 = sb.A, *y = sb.Y;
-    for (int b = 0; b < 8 && b < upto; ++b) {
+    // pass 0 plans the WHOLE stack whatever `upto` is -- the layout of block b's output follows from block b + 1's
+    // readers, and the debug entry point (upto = block + 1) must see the tensors the production call writes
+    for (int b = 0; b < 8 && (b < upto || !go); ++b) {
         const BlockGeo& g = c->stack[b];
         const std::string p = "m" + std::to_string(b);
         const float* cb1 = sb.cb_all + c->cond_off[2 * b];
@@ -477,7 +502,7 @@ float* run_stack_chunk(nhans_ctx* c, const float* logmag, const StackBufs& sb, i
             d.relu = 1; d.out_split = c->prec && !stored_f32(c, plan, 0, 0); d.sat = c->prec ? c->status_dev : nullptr;
             d.out_scale = c->down(SA(0, 0)); d.sat_limit = sat_limit_for(plan, 0, 2);
             d.fdHoWo = make_fastdiv(g.hout * g.wout); d.fdWo = make_fastdiv(g.wout);
-            if (go) {
+            if (go && !dead()) {
                 Prof pr(c, s, "direct_conv64");
                 launch_direct_conv64(d, s);
                 pr.done(2.0 * d.M * g.kh * g.kw * 64, 0);
@@ -538,7 +563,7 @@ float* run_stack_chunk(nhans_ctx* c, const float* logmag, const StackBufs& sb, i
                 t.ws = c->WS(p + ".c2");            // (conv2 and the transform share one column scale: fold.py emit())
                 t.relu = 0; t.out_split = 0;
                 t.in_scale = c->up(SA(b - 1, 1));   // (f32 output: no exponent)
-                if (go) run_conv(c, t, s);
+                if (go && !dead()) run_conv(c, t, s);
                 a = w;
             } else {                        // (x and a1 share one exponent)
                 a.nseg = 2;
@@ -552,7 +577,7 @@ float* run_stack_chunk(nhans_ctx* c, const float* logmag, const StackBufs& sb, i
         if (out == y) std::swap(x, y);
     }
     result = x;
-    if (upto >= 9 && go) {                  // last_conv [5,1] VALID + BN + ReLU  (SN/main.py:232-236)
+    if (upto >= 9 && go && !dead()) {       // last_conv [5,1] VALID + BN + ReLU  (SN/main.py:232-236)
         const BlockGeo& g = c->stack[7];
         ConvArgs a{};
         fill_epilogue_defaults(c, a);
@@ -586,6 +611,7 @@ int mask_net_impl(nhans_ctx* c, const float* logmag, const int64_t* foff, int nc
     for (int64_t g0 = 0; g0 < total; g0 += wf) {
         const int n = (int)std::min<int64_t>(wf, total - g0);
         float* hc = run_stack_chunk(c, logmag, sb, g0, n, 9, s);
+        if (launch_error_pending()) break;      // (reported by the entry point: NHANS_EHIP naming the launch)
         // last_dense 13312 -> 201 (+bias) and denoised = mixed_central + out  (SN/main.py:237-242)
         ConvArgs a{};
         fill_epilogue_defaults(c, a);
@@ -861,10 +887,9 @@ int nhans_create(int model_kind, const void* blob, size_t nbytes, int device_id,
     if (e != hipSuccess) { nhans_destroy(c); return fail(NHANS_EHIP, "weight upload failed"); }
     e = hipHostMalloc(reinterpret_cast<void**>(&c->pin), c->pin_bytes, hipHostMallocDefault);
     if (e != hipSuccess) { nhans_destroy(c); return fail(NHANS_ENOMEM, "pinned staging allocation failed"); }
-    e = hipMalloc(reinterpret_cast<void**>(&c->kscratch), c->kscratch_bytes);
-    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&c->kcounter), c->kcounter_n * sizeof(int));
+    e = hipMalloc(reinterpret_cast<void**>(&c->kcounter), c->kcounter_n * sizeof(int));
     if (e == hipSuccess) e = hipMemset(c->kcounter, 0, c->kcounter_n * sizeof(int));
-    if (e != hipSuccess) { nhans_destroy(c); return fail(NHANS_ENOMEM, "split-K scratch allocation failed"); }
+    if (e != hipSuccess) { nhans_destroy(c); return fail(NHANS_ENOMEM, "split-K ticket allocation failed"); }
     e = hipMalloc(reinterpret_cast<void**>(&c->status_dev), sizeof(int));
     if (e == hipSuccess) e = hipMemset(c->status_dev, 0, sizeof(int));
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&c->amax_dev), kNumAct * sizeof(unsigned));
@@ -987,7 +1012,8 @@ int nhans_set_option(nhans_ctx* c, const char* key, int64_t value) {
         }
     }
     else if (k == "winograd") c->wino = value != 0;
-    else if (k == "winograd_f32_tensors") c->wino_f32 = value == 2 ? 2 : value != 0;
+    else if (k == "winograd_f32_tensors") c->wino_f32 = (value == 2 || value == 3) ? (int)value : value != 0;
+    else if (k == "split_k") c->split_k = value != 0;
     else if (k == "precision") {
         if (value != 0 && value != 1) return fail(NHANS_EINVAL, "precision must be 0 (f32) or 1 (f16x3)");
         if (value == 1 && !c->A("head.dense.wpk_h"))

@@ -32,6 +32,7 @@ constexpr int dev_ablate() { return 0; }
 // failure of the calling thread is kept until the C-ABI entry point collects it with take_launch_error() and returns
 // NHANS_EHIP.  Nothing is launched silently wrong.
 void note_launch(const char* kernel, hipError_t launch_rc);
+bool launch_error_pending();                // a launch of this thread's current call has failed or been refused (not cleared)
 void note_refusal(const char* what);        // a launch the library itself refuses: reported as hipErrorInvalidValue, no HIP state touched
 // hipFuncAttributeMaxDynamicSharedMemorySize is a per-DEVICE attribute: `done_mask` (one static per
 // kernel instantiation) has one bit per device id.
@@ -167,6 +168,7 @@ struct ConvArgs {
 double launch_conv_igemm(const ConvArgs& a, hipStream_t s, const char** kernel = nullptr, double* mfma_flops = nullptr);
 double conv_wino_mfma_flops(const ConvArgs& a);                 // conv_wino.hip
 void launch_conv_igemm_dma(const ConvArgs& a, hipStream_t s);   // conv_igemm_dma.hip
+size_t conv_splitk_scratch_bytes(const ConvArgs& a);            // conv_igemm_dma.hip: scratch its split-K form would need (0: no split)
 bool conv_wino_eligible(const ConvArgs& a);                     // conv_wino.hip
 void launch_conv_wino(const ConvArgs& a, hipStream_t s);
 bool conv_igemm_halo_eligible(const ConvArgs& a);               // conv_igemm_halo.hip

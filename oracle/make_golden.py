@@ -140,6 +140,36 @@ def new_cases_r2():
     np.savez_compressed(OUT + "/case_postproc.npz", **out)
 
 
+def full_10s_cases():
+    """The metric's own clip (BASELINE.json `metric`: RMS vs reference on 10 s / 16 kHz clips; SN/apply.py:189-204,453-458):
+    ALL 998 frames of the 10 s denoiser clip of case_synth10s and the 10 s separator clip of case_separator10s through
+    the float64 path, logits and reconstructed waveform -> tests/golden/case_full10s_<kind>.npz.  Computed with the
+    torch float64 restatement (oracle/torch_ref.py: minutes instead of an hour) and pinned to the numpy oracle on the
+    12 frames the small cases already hold."""
+    import torch
+    from oracle.torch_ref import TorchRef
+    torch.set_num_threads(os.cpu_count() or 1)
+    for kind, seed, small in (("denoiser", 0, "case_synth10s"), ("separator", 5, "case_separator10s")):
+        t0 = time.time()
+        W = weights.synthetic_weights(kind, 7)
+        mix = O.trim_to_frames(O.normalise(synth.mixture(seed, 10.0)))
+        if kind == "denoiser":
+            ca, cb = O.normalise(synth.silent()), O.normalise(synth.noise_context(seed))
+        else:
+            ca, cb = O.normalise(synth.speaker_context(seed, low=True)), O.normalise(synth.speaker_context(seed, low=False))
+        r = TorchRef(W, kind, torch.float64).enhance(mix, ca, cb, faithful=False, mb=50)
+        logits, wav = r["logits"].numpy(), r["denoised_wav"].numpy()
+        g = dict(np.load(os.path.join(OUT, small + ".npz")))
+        fr = g["frames"].astype(np.int64)
+        pin = float(np.abs(logits[fr] - g["logits"]).max())
+        pin_lm = float(np.abs(r["logmag"].numpy() - g["logmag"]).max())
+        print("  %s: %d frames, %d samples in %.0f s; |torch f64 - numpy oracle| on the %d frames of %s: logits %.2e, logmag %.2e"
+              % (kind, logits.shape[0], len(wav), time.time() - t0, len(fr), small, pin, pin_lm), flush=True)
+        assert pin < 1e-6 and pin_lm < 1e-6
+        np.savez_compressed(os.path.join(OUT, "case_full10s_%s.npz" % kind), logits=f32(logits), denoised_wav=f32(wav),
+                            features_case=np.array(small))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     # ---- data fixtures from the reference tree
@@ -197,11 +227,14 @@ def main():
     np.savez_compressed(OUT + "/case_ragged.npz", **allres)
     new_cases_r2()
     demo_tf_fixtures()
+    full_10s_cases()
     print("golden vectors written to", OUT)
 
 
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "demo":      # only the TensorFlow-written demo segments (seconds)
         demo_tf_fixtures()
+    elif len(sys.argv) > 1 and sys.argv[1] == "full10s":  # only the two full-length 10 s cases (minutes)
+        full_10s_cases()
     else:
         main()

@@ -300,3 +300,49 @@ def test_a_calibration_bracket_that_recorded_nothing_keeps_the_exponents(eng):
     assert eng.activation_exponents() == exps
     with pytest.raises(hip.NhansError):
         eng.set_option("calibrate", 3)                                # no bracket is open
+
+
+def test_split_k_stress_is_bit_identical_to_the_unsplit_walk(eng):
+    """conv_igemm_dma.hip's split-K (one workgroup per (tile, K group), partial tiles through scratch, ONE agent-scope
+    release per workgroup, a relaxed ticket, an acquire in the last arriver) against the same launches with option
+    split_k = 0 (every workgroup walks its groups itself, no scratch, no ticket) -- the groups and the order of the
+    additions depend on the layer only, so the bits must agree, launch after launch:
+      * the embedding tower at 10 context images: its 256- and 512-channel convs are 92 and 96 tiles -- the largest
+        grids the split rule admits (<= 96) -- 2,000 tower passes back to back = 10,000 split launches;
+      * the head's dense layer (K = 13,312 in 32 groups, SN/main.py:237-238) at 700 and 1,500 frames, 150 passes each.
+    A lost or stale partial tile (a release that did not cover another wave's stores, a ticket seen before the data)
+    shows up as a differing word."""
+    g = torch.Generator().manual_seed(5)
+    ctx = (torch.randn(10, spec.NOISE_WIN, spec.BINS, generator=g) * 2.0 - 4.0).cuda()
+    try:
+        eng.set_option("split_k", 0)
+        ref_emb = eng.embed(ctx).cpu().numpy()
+        eng.set_option("split_k", 1)
+        eng.set_option("profile", 1)
+        eng.profile_reset()
+        first = eng.embed(ctx).cpu().numpy()
+        names = eng.profile()
+        eng.set_option("profile", 0)
+        assert any("grouped" in k for k in names), names        # the grouped / split-K kernel is what ran
+        assert np.array_equal(first, ref_emb)
+        outs = [eng.embed(ctx) for _ in range(2000)]
+        torch.cuda.synchronize()
+        ref_t = torch.from_numpy(ref_emb).cuda()
+        bad = sum(int(not torch.equal(o, ref_t)) for o in outs)
+        assert bad == 0, "%d of 2000 tower passes differ from the unsplit walk" % bad
+        del outs
+        for nfr in (700, 1500):
+            lm = (torch.randn(nfr, spec.BINS, generator=g) * 2.0 - 4.0).cuda()
+            ea = torch.randn(1, spec.EMB, generator=g).cuda() * 0.1
+            eb = torch.randn(1, spec.EMB, generator=g).cuda() * 0.1
+            eng.set_option("split_k", 0)
+            ref = eng.mask_net(lm, [0, nfr], ea, eb)[0]
+            eng.set_option("split_k", 1)
+            bad = 0
+            for _ in range(150):
+                bad += int(not torch.equal(eng.mask_net(lm, [0, nfr], ea, eb)[0], ref))
+            assert bad == 0, "%d of 150 head passes at %d frames differ from the unsplit walk" % (bad, nfr)
+    finally:
+        eng.set_option("profile", 0)
+        eng.set_option("split_k", 1)
+    assert eng.take_status() == 0

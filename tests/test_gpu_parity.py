@@ -480,3 +480,53 @@ def test_an_f32_stored_tensor_without_a_winograd_reader_is_refused_not_misread(_
     _eng_d.take_status()
     lg = _eng_d.mask_net(lm, [0, 308], ea, eb)[0].cpu().numpy()
     assert np.abs(lg - g["logits"]).max() < LOGIT_TOL
+
+
+def test_a_split_residual_with_an_f32_output_is_refused_by_the_winograd_launcher(_eng_d):
+    """conv_wino's epilogue gives a thread channels {4c..4c+3, 32+4c..} for an f32 output and fetches the residual as
+    two 16-byte pieces of those channels -- a split-NHWC residual does not hold them contiguously (round-5 advisor: the
+    pair was instantiated and silently added the wrong channels).  No plan produces it; winograd_f32_tensors = 3 is the
+    test value that does (only resblock1_2's output f32: its conv2 then reads a split residual and writes f32): the
+    launcher refuses, the call comes back NHANS_EHIP naming it, nothing later of the pass is launched, and the context
+    works again afterwards."""
+    from nhans_amd import hip
+    _eng_d.set_precision("f16x3")
+    g = load_case("case_exp2")
+    lm = torch.from_numpy(g["logmag"]).cuda()
+    ea = torch.from_numpy(g["emb_a"][None]).cuda()
+    eb = torch.from_numpy(g["emb_b"][None]).cuda()
+    try:
+        _eng_d.set_option("winograd_f32_tensors", 3)
+        _eng_d.set_option("profile", 1)
+        _eng_d.profile_reset()
+        with pytest.raises(hip.NhansError) as e:
+            _eng_d.block_output(lm, [0, 308], ea, eb, 100, 2, 1)
+        assert "split residual with an f32-stored output" in str(e.value), str(e.value)
+        with pytest.raises(hip.NhansError):
+            _eng_d.mask_net(lm, [0, 308], ea, eb)
+        calls = {k: v["calls"] for k, v in _eng_d.profile().items()}
+        # the refusal is block 1's conv2: blocks 2 .. 7 and the head (halo / pointwise / grouped kernels) never ran
+        assert not any(k.startswith("conv_igemm_halo_pw") or "grouped" in k for k in calls), calls
+    finally:
+        _eng_d.set_option("profile", 0)
+        _eng_d.set_option("winograd_f32_tensors", 1)
+    torch.cuda.synchronize()
+    _eng_d.take_status()
+    lg = _eng_d.mask_net(lm, [0, 308], ea, eb)[0].cpu().numpy()
+    assert np.abs(lg - g["logits"]).max() < LOGIT_TOL
+
+
+def test_debug_block_output_sees_the_production_layouts(_eng_d):
+    """nhans_debug_block_output(block) launches blocks 0 .. block only, but plans the WHOLE stack (round-5 advisor: with a
+    plan cut at `block` the requested block's conv2 always wrote split NHWC, never the f32 store production uses for the
+    outputs of resblock1_1 / 2_1).  The block outputs agree with the golden taps whichever layout they are stored in."""
+    _eng_d.set_precision("f16x3")
+    g = load_case("case_exp2")
+    lm = torch.from_numpy(g["logmag"]).cuda()
+    ea = torch.from_numpy(g["emb_a"][None]).cuda()
+    eb = torch.from_numpy(g["emb_b"][None]).cuda()
+    tf = [int(f) for f in g["tap_frames"]]
+    for b in (0, 2):                                        # f32-stored in production
+        got = torch.cat([_eng_d.block_output(lm, [0, 308], ea, eb, f, 1, b) for f in tf]).cpu().numpy()
+        ref = g["block%d" % b]
+        assert np.abs(got.reshape(-1)[::97] - ref).max() < 1e-4 * max(1.0, np.abs(ref).max()), b

@@ -204,3 +204,20 @@ def test_tensorflow_written_triples_pin_the_mixing_rule():
     pk = (np.abs(raw).max() + 1e-6) / (np.abs(mixed).max() + 1e-6)
     assert abs(pk - 1.0) > 1e-3
     assert np.abs(pk * mixed.astype(np.float64) - (target.astype(np.float64) + neg_s)).max() < 1e-5
+
+
+def test_full_ten_second_goldens_are_pinned_to_the_numpy_oracle():
+    """tests/golden/case_full10s_<kind>.npz (all 998 frames of the 10 s clips, computed with the torch float64 restatement,
+    oracle/make_golden.py full10s) against what the numpy oracle wrote for the same clips: the 12 frames of logits of
+    case_synth10s / case_separator10s, and the waveform the numpy oracle's own reconstruction (SN/apply.py:189-204) gives
+    from the stored features + the full logits.  Both files hold float32 roundings of float64 values."""
+    for kind, small in (("denoiser", "case_synth10s"), ("separator", "case_separator10s")):
+        full, g = load_case("case_full10s_" + kind), load_case(small)
+        assert full["logits"].shape == (998, 201) and str(full["features_case"]) == small
+        fr = g["frames"].astype(np.int64)
+        assert np.abs(full["logits"][fr] - g["logits"]).max() < 1e-6
+        den = g["logmag"].astype(np.float64) + full["logits"].astype(np.float64)
+        wav = O.recover_samples(den, g["phase"].astype(np.float64))
+        assert wav.shape == full["denoised_wav"].shape
+        assert np.abs(wav - full["denoised_wav"]).max() < 5e-6          # (float32-rounded features and logits in, float32 golden)
+        assert np.isfinite(full["denoised_wav"]).all() and np.abs(full["denoised_wav"]).max() > 0.05
