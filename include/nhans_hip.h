@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define NHANS_ABI_VERSION 4
+#define NHANS_ABI_VERSION 5
 
 #define NHANS_DENOISER 0   /* SN model: emb_a = positive context (--pos), emb_b = negative (--neg) */
 #define NHANS_SEPARATOR 1  /* SS model: emb_a = interferer  (--neg),      emb_b = target   (--pos) */
@@ -86,6 +86,15 @@ int64_t nhans_num_frames(int64_t nsamples);
  * (fold.BLOB_VERSION, 2 since ABI 4); a blob of another version is refused with NHANS_EINVAL -- it would load and compute
  * wrong results -- and the message says to fold the weights again. */
 int nhans_create(int model_kind, const void* folded_blob, size_t nbytes, int device_id, nhans_ctx** out);
+
+/* (ABI 5) The same with the activation exponents handed in -- the NHANS_NUM_ACTIVATIONS values a previous context
+ * reported for THIS blob (nhans_get_activation_exponents after nhans_create): the calibration pass is skipped, which
+ * with a cached folded blob (nhans_amd/blobcache.py) is what brings a cold one-file `nhans_denoiser` call -- the
+ * reference's normal use, SN/apply.py:478-527: one process per file -- under a second.  act_exp == NULL: as nhans_create.
+ * Exponents outside [-60, 60] or n_exp != NHANS_NUM_ACTIVATIONS: NHANS_EINVAL.  Wrong exponents cannot corrupt results
+ * silently: too small raises NHANS_STATUS_SATURATED (Engine redoes the batch in f32), too large costs accuracy bits. */
+int nhans_create_ex(int model_kind, const void* folded_blob, size_t nbytes, int device_id, const int* act_exp, int n_exp,
+                    nhans_ctx** out);
 void nhans_destroy(nhans_ctx* ctx);
 
 /* Options: "frames_per_chunk" (mask-net frame windows per pass, 1..4769 -- the conv kernels address a pass's

@@ -41,7 +41,9 @@ DENOISER_BUNDLE = "81448_0-1000000"      # SN/apply.py:431-432
 SEPARATOR_BUNDLE = "81457_2-545000"      # SS/apply.py:371-372
 
 _engines = {}
+_lite = {}               # torch-free engines of the single-process command line (lite.py)
 _device_index = 0
+TIMING = None            # --timing: dict of the seconds each start-up step took (printed as JSON on stderr)
 
 
 class Flags(object):
@@ -56,6 +58,7 @@ class Flags(object):
     Fs = Fs
     weights = os.environ.get("NHANS_WEIGHTS", "checkpoint")
     model_dir = os.environ.get("NHANS_MODEL_DIR", "./trained_model")
+    cache = True         # folded-blob cache (blobcache.py); --no-cache folds the weights in this process
 
 
 FLAGS = Flags()
@@ -163,10 +166,41 @@ def _load_weights(kind):
 
 
 def get_engine(kind):
+    """The full engine (stage-level entry points, streams, torch tensors): demo / evaluation mode, the sharded
+    multi-GPU command line, tests."""
     if kind not in _engines:
+        if _lite:
+            raise RuntimeError("this process runs the torch-free command-line engine (lite.py); the full engine needs "
+                               "PyTorch's HIP runtime loaded first -- use one or the other in a process")
         from . import engine
         _engines[kind] = engine.Engine(kind, _load_weights(kind), device=_device_index)
     return _engines[kind]
+
+
+def _cache_key(kind):
+    from . import blobcache
+    if FLAGS.weights == "synthetic":
+        return blobcache.key_for_synthetic(kind, 7)
+    bundle = DENOISER_BUNDLE if kind == spec.DENOISER else SEPARATOR_BUNDLE
+    return blobcache.key_for_checkpoint(os.path.join(FLAGS.model_dir, bundle), kind)
+
+
+def get_enhancer(kind):
+    """What the file / directory command line runs on: an engine with .enhance(mixes, ctx_a, ctx_b, want_mixed).  A
+    pre-installed or already built full engine if there is one (set_engine: tests, drivers) or if PyTorch is in the
+    process anyway; otherwise -- a fresh `nhans_denoiser` process, the reference's normal use (SN/apply.py:478-527) --
+    the torch-free LiteEngine on the cached folded blob: no `import torch` (1.5 s), no folding (3 s), no calibration
+    pass."""
+    if kind in _engines:
+        return _engines[kind]
+    if "torch" in sys.modules or int(os.environ.get("WORLD_SIZE", "1")) > 1 or os.environ.get("NHANS_FORCE_TORCH_ENGINE") == "1":
+        return get_engine(kind)
+    if kind not in _lite:
+        os.environ["NHANS_NO_TORCH"] = "1"               # (hip.load: do not pull torch in for its HIP runtime)
+        from . import lite
+        _lite[kind] = lite.cached_engine(kind, _cache_key(kind) if FLAGS.cache else None, lambda: _load_weights(kind),
+                                         device=_device_index, use_cache=FLAGS.cache, timing=TIMING)
+    return _lite[kind]
 
 
 def set_engine(kind, eng):
@@ -178,11 +212,19 @@ def set_engine(kind, eng):
 def _enhance_files(kind, mixedpath, ctx_a_path, ctx_b_path):
     """-> (denoised_samples, mixed_processed_samples) float32 for one file triple; ctx order is
     resnet_block argument order."""
+    import time
+    t0 = time.perf_counter()
     sig = handle_signals(mixedpath, ctx_a_path, ctx_b_path)
     if sig is None:
         raise RuntimeError("could not read %s / %s / %s" % (mixedpath, ctx_a_path, ctx_b_path))
     ca, cb, mixed = sig
-    res = get_engine(kind).enhance([mixed], [ca], [cb], want_mixed=True)
+    t1 = time.perf_counter()
+    eng = get_enhancer(kind)
+    t2 = time.perf_counter()
+    res = eng.enhance([mixed], [ca], [cb], want_mixed=True)
+    if TIMING is not None:
+        TIMING.update(read_wavs_s=t1 - t0, engine_s=t2 - t1, enhance_s=time.perf_counter() - t2,
+                      engine=type(eng).__name__, audio_s=len(mixed) / float(FLAGS.Fs))
     return res["denoised_wav"][0], res["mixed_wav"][0]
 
 
@@ -274,10 +316,11 @@ def apply_batch(kind, jobs):
     own block of files and runs it on its own GPU, one all-gather reassembles the waveforms (a job
     whose files could not be read travels as length -1, dist.gather_ragged) and rank 0 writes the files.
     Returns the number of clips written by this rank."""
-    import torch
-    from . import dist as nd
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
+    if world > 1:
+        import torch
+        from . import dist as nd
     lo, hi = nd.shard_bounds(len(jobs), world, rank) if world > 1 else (0, len(jobs))
     sigs = []
     for mixedpath, pospath, negpath, _ in jobs[lo:hi]:
@@ -286,7 +329,7 @@ def apply_batch(kind, jobs):
     good = [s for s in sigs if s is not None]
     if world == 1 and not good:
         return 0
-    eng = get_engine(kind)
+    eng = get_enhancer(kind)
     done = iter(_enhance_in_calls(eng, [s[2] for s in good], [s[0] for s in good], [s[1] for s in good]))
     outs = [None if s is None else next(done) for s in sigs]
     if world > 1:
@@ -423,6 +466,10 @@ def _parse(argv, prog):
     p.add_argument('--ac', action='store_true')
     p.add_argument('--weights', default=FLAGS.weights, choices=['checkpoint', 'synthetic'])
     p.add_argument('--model_dir', default=FLAGS.model_dir)
+    p.add_argument('--no-cache', dest='cache', action='store_false', default=True,
+                   help='fold the weights in this process instead of reading / writing the folded-blob cache '
+                        '($NHANS_CACHE_DIR or ~/.cache/nhans_amd: blobcache.py)')
+    p.add_argument('--timing', action='store_true', help='print the seconds of each start-up step as JSON on stderr')
     p.add_argument('--no-convert', dest='convert', action='store_false', default=True,
                    help='reject inputs that are not 16 kHz int16 PCM (in-tree reference behaviour) '
                         'instead of converting them (packaged-tool behaviour, README.md:42)')
@@ -447,6 +494,22 @@ def _pairs(a):
 
 
 def _run_cli(kind, a):
+    global TIMING
+    import time
+    t0 = time.perf_counter()
+    TIMING = {} if getattr(a, "timing", False) else None
+    try:
+        _run_cli_jobs(kind, a)
+    finally:
+        if TIMING is not None:
+            import json
+            TIMING["run_cli_s"] = time.perf_counter() - t0
+            TIMING["torch_imported"] = "torch" in sys.modules
+            sys.stderr.write("nhans timing: " + json.dumps(TIMING) + "\n")
+            TIMING = None
+
+
+def _run_cli_jobs(kind, a):
     jobs = list(_pairs(a))
     if os.path.isdir(a.input) or int(os.environ.get("WORLD_SIZE", "1")) > 1:
         _bind_rank_device()

@@ -862,8 +862,18 @@ static int calibrate_builtin(nhans_ctx* c) {
 }
 
 int nhans_create(int model_kind, const void* blob, size_t nbytes, int device_id, nhans_ctx** out) {
+    return nhans_create_ex(model_kind, blob, nbytes, device_id, nullptr, 0, out);
+}
+
+int nhans_create_ex(int model_kind, const void* blob, size_t nbytes, int device_id, const int* act_exp, int n_exp,
+                    nhans_ctx** out) {
     if (!out || !blob) return fail(NHANS_EINVAL, "null argument");
     *out = nullptr;
+    if (act_exp) {
+        if (n_exp != kNumAct) return fail(NHANS_EINVAL, "activation exponents: need NHANS_NUM_ACTIVATIONS values");
+        for (int i = 0; i < n_exp; ++i)
+            if (act_exp[i] < -60 || act_exp[i] > 60) return fail(NHANS_EINVAL, "activation exponent outside [-60, 60]");
+    }
     if (model_kind != NHANS_DENOISER && model_kind != NHANS_SEPARATOR) return fail(NHANS_EINVAL, "bad model_kind");
     if (nbytes < sizeof(BlobHeader)) return fail(NHANS_EINVAL, "blob too short");
     const BlobHeader* h = static_cast<const BlobHeader*>(blob);
@@ -946,7 +956,11 @@ int nhans_create(int model_kind, const void* blob, size_t nbytes, int device_id,
             return fail(NHANS_EINVAL, msg);
         }
     }
-    if (c->A("head.dense.wpk_h")) {
+    if (act_exp) {
+        // (exponents a previous context calibrated for this very blob -- the caller's cache vouches for that: no pass)
+        std::copy(act_exp, act_exp + kNumAct, c->act_exp);
+        tie_exponents(c);
+    } else if (c->A("head.dense.wpk_h")) {
         const int rc = calibrate_builtin(c);
         if (rc) { nhans_destroy(c); return rc; }
     }

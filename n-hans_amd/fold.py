@@ -350,3 +350,12 @@ def write_blob(arrays):
 def fold_weights(W, kind):
     """Checkpoint dict -> blob bytes for nhans_create()."""
     return write_blob(fold_arrays(W, kind))
+
+
+def blob_header_ok(blob):
+    """Does this byte buffer (bytes / uint8 array) start with a header of THIS packing version that describes its own
+    length?  (blobcache.py: a cached blob of another version, or a truncated file, is rebuilt.)"""
+    if len(blob) < 24:
+        return False
+    magic, version, _, total = struct.unpack("<8sIIQ", bytes(blob[:24]))
+    return magic == b"NHANSFW1" and version == BLOB_VERSION and total == len(blob)

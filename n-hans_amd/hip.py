@@ -5,6 +5,7 @@ There is no CPU fallback: if the shared library is missing or fails to load, eve
 import ctypes
 import json
 import os
+import sys
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # ($NHANS_LIB: another build of the same library for a same-box A/B of two kernels -- a developer convenience of this
@@ -15,7 +16,7 @@ DENOISER, SEPARATOR = 0, 1
 KIND_CODE = {"denoiser": DENOISER, "separator": SEPARATOR}
 
 EXPORTS = [
-    "nhans_abi_version", "nhans_last_error", "nhans_num_frames", "nhans_create", "nhans_destroy",
+    "nhans_abi_version", "nhans_last_error", "nhans_num_frames", "nhans_create", "nhans_create_ex", "nhans_destroy",
     "nhans_set_option", "nhans_workspace_bytes", "nhans_stft_features", "nhans_embed",
     "nhans_mask_net", "nhans_istft", "nhans_enhance_clips", "nhans_debug_block_output",
     "nhans_profile_json", "nhans_profile_reset", "nhans_take_status", "nhans_debug_launch_probe", "nhans_crc32c",
@@ -24,7 +25,7 @@ EXPORTS = [
 ]
 STATUS_SATURATED = 1
 NUM_ACTIVATIONS = 25
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 _lib = None
 
@@ -41,7 +42,11 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise NhansError("%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                          "or `make -C n-hans_amd/csrc` (there is no CPU fallback)" % LIB_PATH)
-    import torch  # noqa: F401  -- makes torch's libamdhip64.so.7 the process-wide HIP runtime first
+    # With torch in the process its bundled libamdhip64.so.7 must be THE HIP runtime (two runtimes in one process do not
+    # share devices or streams): torch is imported first unless the caller has said this process stays torch-free
+    # (NHANS_NO_TORCH=1, set by the single-process command line: lite.py) -- importing it costs more than a one-file call.
+    if os.environ.get("NHANS_NO_TORCH") != "1" or "torch" in sys.modules:
+        import torch  # noqa: F401
     lib = ctypes.CDLL(LIB_PATH)
     vp, i64p = ctypes.c_void_p, ctypes.POINTER(ctypes.c_int64)
     lib.nhans_abi_version.restype = ctypes.c_int
@@ -49,6 +54,8 @@ def load():
     lib.nhans_num_frames.restype = ctypes.c_int64
     lib.nhans_num_frames.argtypes = [ctypes.c_int64]
     lib.nhans_create.argtypes = [ctypes.c_int, vp, ctypes.c_size_t, ctypes.c_int, ctypes.POINTER(vp)]
+    lib.nhans_create_ex.argtypes = [ctypes.c_int, vp, ctypes.c_size_t, ctypes.c_int, ctypes.POINTER(ctypes.c_int), ctypes.c_int,
+                                    ctypes.POINTER(vp)]
     lib.nhans_destroy.argtypes = [vp]
     lib.nhans_destroy.restype = None
     lib.nhans_set_option.argtypes = [vp, ctypes.c_char_p, ctypes.c_int64]
@@ -73,7 +80,7 @@ def load():
     lib.nhans_get_activation_amax.argtypes = [vp, ctypes.POINTER(ctypes.c_float), ctypes.c_int]
     lib.nhans_crc32c.argtypes = [ctypes.c_uint32, vp, ctypes.c_size_t]
     lib.nhans_crc32c.restype = ctypes.c_uint32
-    for name in ("nhans_create", "nhans_set_option", "nhans_stft_features", "nhans_embed", "nhans_mask_net",
+    for name in ("nhans_create", "nhans_create_ex", "nhans_set_option", "nhans_stft_features", "nhans_embed", "nhans_mask_net",
                  "nhans_istft", "nhans_enhance_clips", "nhans_debug_block_output", "nhans_profile_json",
                  "nhans_profile_reset", "nhans_take_status", "nhans_debug_launch_probe",
                  "nhans_set_activation_exponents", "nhans_get_activation_exponents", "nhans_get_activation_amax"):

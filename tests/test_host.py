@@ -7,6 +7,7 @@ import os
 import re
 import struct
 import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -241,7 +242,7 @@ def test_library_exports_every_declared_symbol(lib_built):
     for name in declared:
         assert hasattr(lib, name), name
     h = hip.load()
-    assert h.nhans_abi_version() == hip.ABI_VERSION == 4
+    assert h.nhans_abi_version() == hip.ABI_VERSION == 5
     assert h.nhans_num_frames(399) == 0 and h.nhans_num_frames(400) == 1 and h.nhans_num_frames(159920) == 998
     bad = ctypes.create_string_buffer(b"x" * 64, 64)
     out = ctypes.c_void_p()
@@ -701,3 +702,51 @@ def test_winograd_kernel_wait_counts_by_model():
     for nc in (2, 4, 8, 16, 32):
         for early in (True, False):
             run(nc, early)
+
+
+def test_blob_cache_round_trip_and_staleness(tmp_path, monkeypatch):
+    """blobcache.py: an entry comes back byte for byte with its exponents; a truncated blob, a blob of another packing
+    version and an entry without its json are ignored (None -> the caller folds again); the key moves with the model kind,
+    the seed, the ABI version and fold.BLOB_VERSION."""
+    from nhans_amd import blobcache, fold
+    monkeypatch.setenv("NHANS_CACHE_DIR", str(tmp_path))
+    arrays = {"zero": np.zeros(64, np.float32), "tw400": np.arange(800, dtype=np.float32)}
+    blob = fold.write_blob(arrays)
+    assert fold.blob_header_ok(blob) and not fold.blob_header_ok(blob[:-1]) and not fold.blob_header_ok(b"x" * 100)
+    assert blobcache.load("k1") is None
+    assert blobcache.store("k1", blob, list(range(hip.NUM_ACTIVATIONS)))
+    got = blobcache.load("k1")
+    assert got is not None and got[0].tobytes() == blob and got[1] == list(range(hip.NUM_ACTIVATIONS))
+    with open(os.path.join(str(tmp_path), "k1.blob"), "r+b") as f:
+        f.truncate(len(blob) - 256)
+    assert blobcache.load("k1") is None
+    other = bytearray(blob)
+    other[8:12] = (fold.BLOB_VERSION + 1).to_bytes(4, "little")
+    assert blobcache.store("k2", bytes(other)) and blobcache.load("k2") is None
+    assert blobcache.store("k3", blob) and blobcache.load("k3")[1] is None          # (no exponents yet)
+    os.remove(os.path.join(str(tmp_path), "k3.json"))
+    assert blobcache.load("k3") is None
+    keys = {blobcache.key_for_synthetic("denoiser", 7), blobcache.key_for_synthetic("separator", 7), blobcache.key_for_synthetic("denoiser", 8)}
+    monkeypatch.setattr(fold, "BLOB_VERSION", fold.BLOB_VERSION + 1)
+    keys.add(blobcache.key_for_synthetic("denoiser", 7))
+    monkeypatch.setattr(hip, "ABI_VERSION", hip.ABI_VERSION + 1)
+    keys.add(blobcache.key_for_synthetic("denoiser", 7))
+    assert len(keys) == 5
+    # a TensorFlow bundle is keyed by its .index bytes (shapes, offsets, per-tensor crc32c) and its data size
+    import shutil
+    pre = os.path.join(str(tmp_path), "m")
+    shutil.copyfile(os.path.join(GOLDEN, "denoiser.index"), pre + ".index")
+    open(pre + ".data-00000-of-00001", "wb").write(b"0" * 134)
+    k_a = blobcache.key_for_checkpoint(pre, "denoiser")
+    open(pre + ".data-00000-of-00001", "wb").write(b"0" * 135)
+    assert blobcache.key_for_checkpoint(pre, "denoiser") != k_a
+
+
+def test_the_command_line_modules_do_not_import_torch():
+    """lite.py / hiprt.py / blobcache.py / apply.py must stay importable without PyTorch: the one-file command line never
+    pays for `import torch` (checked end to end on the GPU box: tests/test_gpu_cold_call.py)."""
+    import subprocess
+    code = ("import sys; sys.path.insert(0, %r); import nhans_amd; from nhans_amd import apply, blobcache, hiprt, lite; "
+            "assert 'torch' not in sys.modules, 'torch imported'; print('ok')" % ROOT)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True)
+    assert out.returncode == 0 and out.stdout.strip() == "ok", out.stderr
