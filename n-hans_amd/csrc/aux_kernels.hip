@@ -29,12 +29,13 @@ __global__ void __launch_bounds__(256) direct_conv64(const DirectArgs a) {
         const uint32_t rem = (uint32_t)m - b * a.fdHoWo.d;
         const uint32_t ho = fd_div(rem, a.fdWo);
         const uint32_t wo = rem - ho * a.fdWo.d;
-        const float* img = a.src + (size_t)b * a.H * a.W;
+        const float* img = a.win.t ? a.src + ((ptrdiff_t)a.win.row0 + (ptrdiff_t)b) * a.W : a.src + (size_t)b * a.H * a.W;
         const int hi0 = (int)ho * a.sh - a.pt, wi0 = (int)wo * a.sw - a.pl;
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
         for (int kh = 0; kh < a.KH; ++kh) {
             const int hi = hi0 + kh;
             if ((unsigned)hi >= (unsigned)a.H) continue;
+            if (a.win.t && !win_row_ok(a.win, (int)b, hi)) continue;      // (a zero row adds 0 * w: skipped like padding)
             for (int kw = 0; kw < a.KW; ++kw) {
                 const int wi = wi0 + kw;
                 if ((unsigned)wi >= (unsigned)a.W) continue;
@@ -77,41 +78,56 @@ __global__ void __launch_bounds__(256) direct_conv64(const DirectArgs a) {
     }
 }
 
-// The 4x4 case (resblock1_1_conv1: 7,035 pixels per frame-window, 4 % of a step when done by the
-// generic kernel above, whose 16 global loads per thread sit in a branchy loop): persistent blocks,
-// the thread's 16 x 4 weights live in registers, a block takes 4 x 16 output pixels at a time and
-// stages their zero-padded input patch in LDS once, so the inner loop is 16 LDS reads + 64 FMAs.
-// Same taps in the same order as the generic kernel (a padded tap adds 0 * w): bitwise the same.
+// The 4x4 case (resblock1_1_conv1: 7,035 pixels per frame-window; a pure HBM writer -- 6.7 GB per pass of 3,776 frames
+// against 0.1 GB read): persistent blocks, the thread's 16 x 4 weights live in registers, a block takes D4_TR x 16
+// output pixels at a time from their zero-padded input patch in LDS, so the inner loop is 16 LDS values + 64 FMAs
+// (32 v_pk_fma_f32) per 16-byte store.  Same taps in the same order as the generic kernel (a padded tap adds 0 * w):
+// bitwise the same.
+// Round 6: (i) the input is read where it lies -- `win` makes frame b's 35 x 201 image a sliding window of the
+// log-magnitude spectrogram (SN/apply.py:378's strided_crop never materialised: the gather_windows kernel and its 104 MB
+// per pass are gone); (ii) the patch of the NEXT tile is fetched into registers before the current one is computed and
+// parked in the other LDS buffer afterwards -- one barrier per tile instead of two, no global-load latency between
+// tiles; (iii) tiles of 7 rows (35 = 5 x 7: no skipped pass) instead of 4.  A pure store stream of this shape reaches
+// 6.4-6.6 TB/s on the chip (tools/ubench/store_stream.hip, profiles/r06); the kernel stood at 3.97.
+constexpr int D4_TR = 7, D4_PATCH = 256;           // rows per tile; floats per patch buffer ((D4_TR + 3) x 19 = 190 at stride 1)
 template <int SPLIT>
 __global__ void __launch_bounds__(256) direct_conv64_4x4(const DirectArgs a, int tiles_r, int tiles_c, int ntiles) {
-    __shared__ float patch[1024];
+    __shared__ float patch[2][D4_PATCH];
     const int cq = threadIdx.x & 15, c = cq * 4, pc = threadIdx.x >> 4;
     float4 w[16];
 #pragma unroll
     for (int t = 0; t < 16; ++t) w[t] = *reinterpret_cast<const float4*>(a.w + t * 64 + c);
-    const int PH = 3 * a.sh + 4, PW = 15 * a.sw + 4;
+    const int PH = (D4_TR - 1) * a.sh + 4, PW = 15 * a.sw + 4;
     const int tpi = tiles_r * tiles_c;
+    const int pi_h = (int)threadIdx.x / PW, pi_w = (int)threadIdx.x - pi_h * PW;     // this thread's patch element
+    const bool pi_ok = (int)threadIdx.x < PH * PW;
+    // element `threadIdx.x` of tile `tile`'s patch (0.0: padding, a row outside the clip, no such tile)
+    auto fetch = [&](int tile) -> float {
+        if (tile >= ntiles || !pi_ok) return 0.f;
+        const int b = tile / tpi, q = tile - b * tpi;
+        const int tr = q / tiles_c;
+        const int hi = tr * D4_TR * a.sh - a.pt + pi_h, wi = (q - tr * tiles_c) * 16 * a.sw - a.pl + pi_w;
+        if ((unsigned)hi >= (unsigned)a.H || (unsigned)wi >= (unsigned)a.W) return 0.f;
+        if (a.win.t) return win_row_ok(a.win, b, hi) ? a.src[((ptrdiff_t)a.win.row0 + b + hi) * a.W + wi] : 0.f;
+        return a.src[((size_t)b * a.H + hi) * a.W + wi];
+    };
+    int cur = 0;
+    patch[0][threadIdx.x] = fetch(blockIdx.x);
+    __syncthreads();
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const float nxt = fetch(tile + gridDim.x);             // in flight under this tile's arithmetic
         const int b = tile / tpi;
         const int q = tile - b * tpi;
         const int tr = q / tiles_c;
-        const int ho0 = tr * 4, wo0 = (q - tr * tiles_c) * 16;
-        const int hi0 = ho0 * a.sh - a.pt, wi0 = wo0 * a.sw - a.pl;
-        const float* img = a.src + (size_t)b * a.H * a.W;
-        __syncthreads();                                   // the previous tile's readers are done
-        for (int i = threadIdx.x; i < PH * PW; i += 256) {
-            const int ph = i / PW, pw = i - ph * PW;
-            const int hi = hi0 + ph, wi = wi0 + pw;
-            patch[i] = ((unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W) ? img[hi * a.W + wi] : 0.f;
-        }
-        __syncthreads();
+        const int ho0 = tr * D4_TR, wo0 = (q - tr * tiles_c) * 16;
         const int clip = a.img_clip ? a.img_clip[b] : 0;
         const float4 cb = *reinterpret_cast<const float4*>(a.cb + (size_t)clip * a.cb_stride + c);
+        const float* const pbuf = patch[cur];
 #pragma unroll 1
-        for (int pass = 0; pass < 4; ++pass) {
+        for (int pass = 0; pass < D4_TR; ++pass) {
             const int ho = ho0 + pass, wo = wo0 + pc;
             if (ho >= a.Ho || wo >= a.Wo) continue;
-            const float* px = patch + (pass * a.sh) * PW + pc * a.sw;
+            const float* px = pbuf + (pass * a.sh) * PW + pc * a.sw;
             float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
             for (int t = 0; t < 16; ++t) {
@@ -155,6 +171,10 @@ __global__ void __launch_bounds__(256) direct_conv64_4x4(const DirectArgs a, int
                 }
             }
         }
+        // the next tile's patch into the other buffer: its last readers passed the barrier at the end of the previous turn
+        patch[cur ^ 1][threadIdx.x] = nxt;
+        __syncthreads();
+        cur ^= 1;
     }
 }
 
@@ -219,8 +239,9 @@ void launch_absmax(const float* x, size_t nwords, int split, float scale, unsign
 }
 
 void launch_direct_conv64(const DirectArgs& a, hipStream_t s) {
-    if (a.KH == 4 && a.KW == 4 && a.sh <= 3 && a.sw <= 3 && a.M % (a.Ho * a.Wo) == 0) {
-        const int tiles_r = (a.Ho + 3) / 4, tiles_c = (a.Wo + 15) / 16;
+    const int ph4 = (D4_TR - 1) * a.sh + 4, pw4 = 15 * a.sw + 4;
+    if (a.KH == 4 && a.KW == 4 && ph4 * pw4 <= D4_PATCH && a.M % (a.Ho * a.Wo) == 0) {
+        const int tiles_r = (a.Ho + D4_TR - 1) / D4_TR, tiles_c = (a.Wo + 15) / 16;
         const int ntiles = (a.M / (a.Ho * a.Wo)) * tiles_r * tiles_c;
         const int grid4 = ntiles < 256 * 8 ? ntiles : 256 * 8;
         if (a.out_split) NHANS_LAUNCH("direct_conv64_4x4", direct_conv64_4x4<1>, dim3(grid4), dim3(256), 0, s, a, tiles_r, tiles_c, ntiles);
@@ -252,30 +273,6 @@ void launch_frame_index(const int64_t* frame_offsets_dev, int nclips, int64_t to
     if (total <= 0) return;
     NHANS_LAUNCH("frame_index", frame_index_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s,
                        frame_offsets_dev, nclips, total, f_clip, f_t, f_T);
-}
-
-// Sliding 35-frame windows (strided_crop, SN/apply.py:170-186,378): row h of frame g's window is
-// log-magnitude row t+h-17 of the same clip, or 0.0 (NOT the silence floor) outside [0, T).
-__global__ void __launch_bounds__(256) gather_windows_kernel(const float* logmag, const int* f_t,
-                                                             const int* f_T, int64_t g0, int n, float* xw) {
-    const int per = kMixWin * kBins;
-    const int64_t total = (int64_t)n * per;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-        const int f = (int)(i / per);
-        const int r = (int)(i - (int64_t)f * per);
-        const int h = r / kBins, w = r - h * kBins;
-        const int64_t g = g0 + f;
-        const int tt = f_t[g] + h - kCenter;
-        xw[i] = (tt >= 0 && tt < f_T[g]) ? logmag[(g + h - kCenter) * kBins + w] : 0.f;
-    }
-}
-
-void launch_gather_windows(const float* logmag, const int* f_t, const int* f_T, int64_t g0, int n, float* xw,
-                           hipStream_t s) {
-    if (n <= 0) return;
-    int64_t blocks = ((int64_t)n * kMixWin * kBins + 255) / 256;
-    if (blocks > 256 * 32) blocks = 256 * 32;
-    NHANS_LAUNCH("gather_windows", gather_windows_kernel, dim3((unsigned)blocks), dim3(256), 0, s, logmag, f_t, f_T, g0, n, xw);
 }
 
 // ---------------------------------------------------------------------------------------------

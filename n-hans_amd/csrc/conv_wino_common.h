@@ -69,6 +69,17 @@ __device__ __forceinline__ void wino_epilogue(const ConvArgs& a, const f32x16 (*
     // in L2 and came from HBM again almost once per frame).  An absent table reads the zero page.
     const float lo_clamp = a.relu ? 0.f : -3.0e38f;
 
+    // (IDM 3 with a sliding-window image: the frame's position in its clip and the clip's length -- uniform, SCALAR loads,
+    // here in front of the counted vector-memory requests; a plain image: every row valid)
+    int win_t = a.id_win.pad, win_T = 0x7fffffff;
+    if constexpr (IDM == 3) {
+        if (a.id_win.t) {
+            const int bu = __builtin_amdgcn_readfirstlane(b);
+            win_t = a.id_win.t[bu];
+            win_T = a.id_win.T[bu];
+        }
+    }
+
     // 0. the per-channel constants (ws, bias, idw of the block's 64 channels), fetched by the eight threads of
     // tile-pixel 0 BEFORE the residual requests -- loads return in order, so a constant fetched after them could not be
     // used until every residual has arrived -- and handed to everybody through LDS with the accumulator tiles
@@ -161,8 +172,13 @@ __device__ __forceinline__ void wino_epilogue(const ConvArgs& a, const f32x16 (*
             rh[i] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(idb + o));
             rl[i] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(idb + o + CHB * 4));
         } else if constexpr (IDM == 3) {
-            const int ids0 = (b * a.idH + (okq ? ho : 0) * a.idsh) * a.idW + (okq ? wo0 : 0) * a.idsw;
-            rsv[i] = a.id[ids0 + (i < lastc ? i : lastc) * a.idsw];
+            // one-channel image; with id_win a sliding window of a.id (the log-magnitude spectrogram itself, round 6): a row
+            // outside the clip is a row of zeros -- the address is selected (the zero page, stride 0), the load unconditional
+            const int hrow = (okq ? ho : 0) * a.idsh;
+            const bool rowok = (unsigned)(win_t + hrow - a.id_win.pad) < (unsigned)win_T;
+            const int ids0 = (a.id_win.t ? (a.id_win.row0 + b + hrow) : (b * a.idH + hrow)) * a.idW + (okq ? wo0 : 0) * a.idsw;
+            const float* const idp = rowok ? a.id + ids0 : a.zero;
+            rsv[i] = idp[rowok ? (i < lastc ? i : lastc) * a.idsw : 0];
         }
     };
 #pragma unroll

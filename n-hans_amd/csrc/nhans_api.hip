@@ -422,7 +422,7 @@ size_t stack_buf_floats(const nhans_ctx* c, int64_t wf) {
 // ---- conditioned stack + head ---------------------------------------------------------------
 struct StackBufs {
     int* f_clip; int* f_t; int* f_T; int64_t* foff_dev; float* cb_all;
-    float* xw; float* X; float* A; float* Y;
+    float* X; float* A; float* Y;
     float* T;       // f32 output of a block's 1x1 `_transform` conv when its conv2 runs in Winograd form
 };
 
@@ -437,7 +437,7 @@ size_t transform_buf_floats(const nhans_ctx* c, int64_t wf) {
 
 size_t stack_ws_bytes(const nhans_ctx* c, int64_t total, int nclips, int64_t wf) {
     size_t b = 3 * ws_size(total, 4) + ws_size(nclips + 1, 8) + ws_size((size_t)nclips * c->cond_cols, 4);
-    b += ws_size((size_t)wf * kMixWin * kBins, 4) + 3 * ws_size(stack_buf_floats(c, wf), 4);
+    b += 3 * ws_size(stack_buf_floats(c, wf), 4);
     b += ws_size(transform_buf_floats(c, wf), 4);
     return b;
 }
@@ -446,7 +446,6 @@ void stack_take(nhans_ctx* c, int64_t total, int nclips, int64_t wf, StackBufs* 
     sb->f_clip = ws_take<int>(c, total); sb->f_t = ws_take<int>(c, total); sb->f_T = ws_take<int>(c, total);
     sb->foff_dev = ws_take<int64_t>(c, nclips + 1);
     sb->cb_all = ws_take<float>(c, (size_t)nclips * c->cond_cols);
-    sb->xw = ws_take<float>(c, (size_t)wf * kMixWin * kBins);
     const size_t nb = stack_buf_floats(c, wf);
     sb->X = ws_take<float>(c, nb); sb->A = ws_take<float>(c, nb); sb->Y = ws_take<float>(c, nb);
     sb->T = ws_take<float>(c, transform_buf_floats(c, wf));
@@ -477,11 +476,10 @@ float* run_stack_chunk(nhans_ctx* c, const float* logmag, const StackBufs& sb, i
         }
         run_conv(c, a, s);
     };
-    if (go) {
-        Prof pr(c, s, "gather_windows");
-        launch_gather_windows(logmag, sb.f_t, sb.f_T, g0, n, sb.xw, s);
-        pr.done(0, (double)n * kMixWin * kBins * 8);
-    }
+    // frame b's 35 x 201 image = rows g0 + b - 17 ... of the log-magnitude spectrogram, zero rows outside its clip
+    // (SN/apply.py:170-186,378: strided_crop, never materialised -- the first conv and the 1 -> 64 residual of
+    // resblock1_1 read the spectrogram where it lies)
+    const WinRows win{sb.f_t + g0, sb.f_T + g0, (int)g0 - kCenter, kCenter};
     float *x = sb.X, *a1 = sb.A, *y = sb.Y;
     // pass 0 plans the WHOLE stack whatever `upto` is -- the layout of block b's output follows from block b + 1's
     // readers, and the debug entry point (upto = block + 1) must see the tensors the production call writes
@@ -492,7 +490,7 @@ float* run_stack_chunk(nhans_ctx* c, const float* logmag, const StackBufs& sb, i
         const float* cb2 = sb.cb_all + c->cond_off[2 * b + 1];
         if (b == 0) {
             DirectArgs d{};
-            d.src = sb.xw; d.w = c->A(p + ".c1.w"); d.H = g.hin; d.W = g.win; d.KH = g.kh; d.KW = g.kw;
+            d.src = logmag; d.win = win; d.w = c->A(p + ".c1.w"); d.H = g.hin; d.W = g.win; d.KH = g.kh; d.KW = g.kw;
             d.sh = 1; d.sw = 1;
             int o; same_pad(g.hin, g.kh, 1, &o, &d.pt); same_pad(g.win, g.kw, 1, &o, &d.pl);
             d.Ho = g.hout; d.Wo = g.wout; d.M = n * g.hout * g.wout; d.out = a1;
@@ -537,7 +535,7 @@ float* run_stack_chunk(nhans_ctx* c, const float* logmag, const StackBufs& sb, i
         a.in_f32 = stored_f32(c, plan, b, 0); a.out_split = c->prec && !stored_f32(c, plan, b, 1);
         float* out;
         if (b == 0) {                       // 1 -> 64 transform on the window image itself
-            a.id_mode = 2; a.id = sb.xw; a.idH = g.hin; a.idW = g.win; a.idsh = 1; a.idsw = 1;
+            a.id_mode = 2; a.id = logmag; a.id_win = win; a.idH = g.hin; a.idW = g.win; a.idsh = 1; a.idsw = 1;
             out = x;
         } else if (g.cin == g.cout) {       // identity shortcut, written in place over the block input
             a.id_mode = 1; a.id = x; a.id_ld = g.cout; a.id_split = c->prec && !stored_f32(c, plan, b - 1, 1);

@@ -77,6 +77,20 @@ __device__ __forceinline__ uint32_t fd_div(uint32_t n, const FastDiv& f) {
     return (__umulhi(f.mul, n) + n) >> f.sh;
 }
 
+// A batch of 1-channel "images" that are SLIDING WINDOWS of one [rows, W] tensor: image b's row h is tensor row
+// row0 + b + h when 0 <= t[b] + h - pad < T[b] (t: the frame's position in its clip, T: the clip's length), and a row of
+// 0.0 otherwise -- strided_crop of SN/apply.py:170-186,378 (35-row windows of the log-magnitude spectrogram, zero rows
+// -- not the silence floor -- outside the clip) without ever materialising [T, 35, 201].
+// t == nullptr: plain images [B, H, W].
+struct WinRows {
+    const int* t;
+    const int* T;
+    int row0, pad;
+};
+__device__ __forceinline__ bool win_row_ok(const WinRows& w, int b, int h) {
+    return (unsigned)(w.t[b] + h - w.pad) < (unsigned)w.T[b];
+}
+
 // ---------------------------------------------------------------------------------------------
 // Implicit-GEMM convolution on the f32 matrix cores (conv_igemm.hip).
 //   out[m, n] = epilogue( sum_seg sum_{kh,kw,c} src_seg[b, ho*sh+kh-pt, wo*sw+kw-pl, c] * W_seg[kh,kw,c,n] )
@@ -115,6 +129,7 @@ struct ConvArgs {
     int id_ld;
     const float* idw;
     int idH, idW, idsh, idsw;
+    WinRows id_win;        // id_mode 2: the image is a sliding window of `id` (idH is then unused)
     int relu;
     float* aux;
     int aux_ld;
@@ -179,7 +194,8 @@ void launch_conv_igemm_halo_pw(const ConvArgs& a, hipStream_t s);
 // ---------------------------------------------------------------------------------------------
 // Small kernels (aux_kernels.hip)
 struct DirectArgs {     // convolution of a 1-channel image into 64 channels, same epilogue terms
-    const float* src;   // [B, H, W]
+    const float* src;   // [B, H, W] -- or, win.t != nullptr, the [rows, W] tensor the images are sliding windows of
+    WinRows win;
     const float* w;     // [KH*KW][64], BN scale folded in
     int H, W, KH, KW, sh, sw, pt, pl, Ho, Wo;
     int M;              // B*Ho*Wo
@@ -208,9 +224,6 @@ void launch_absmax(const float* x, size_t nwords, int split, float scale, unsign
 // frame index: for global frame g -> clip, t within clip, T of clip
 void launch_frame_index(const int64_t* frame_offsets_dev, int nclips, int64_t total, int* f_clip,
                         int* f_t, int* f_T, hipStream_t s);
-// xw[i, h, w] = logmag row (g0+i) - t + (t+h-17) or 0.0 outside the clip   (SN/apply.py:170-186)
-void launch_gather_windows(const float* logmag, const int* f_t, const int* f_T, int64_t g0, int n,
-                           float* xw, hipStream_t s);
 // mean over HW positions, times `scale`: x [B, HW, C] -> out [B, C]
 void launch_avgpool(const float* x, int B, int HW, int C, int split, float scale, float* out, hipStream_t s);
 // cb[clip, n] = base[n] + sum_k ea[clip,k]*Wc[k, n] + sum_k eb[clip,k]*Wc[512+k, n]
