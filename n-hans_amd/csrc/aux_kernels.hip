@@ -78,101 +78,140 @@ __global__ void __launch_bounds__(256) direct_conv64(const DirectArgs a) {
     }
 }
 
-// The 4x4 case (resblock1_1_conv1: 7,035 pixels per frame-window; a pure HBM writer -- 6.7 GB per pass of 3,776 frames
-// against 0.1 GB read): persistent blocks, the thread's 16 x 4 weights live in registers, a block takes D4_TR x 16
-// output pixels at a time from their zero-padded input patch in LDS, so the inner loop is 16 LDS values + 64 FMAs
-// (32 v_pk_fma_f32) per 16-byte store.  Same taps in the same order as the generic kernel (a padded tap adds 0 * w):
-// bitwise the same.
-// Round 6: (i) the input is read where it lies -- `win` makes frame b's 35 x 201 image a sliding window of the
-// log-magnitude spectrogram (SN/apply.py:378's strided_crop never materialised: the gather_windows kernel and its 104 MB
-// per pass are gone); (ii) the patch of the NEXT tile is fetched into registers before the current one is computed and
-// parked in the other LDS buffer afterwards -- one barrier per tile instead of two, no global-load latency between
-// tiles; (iii) tiles of 7 rows (35 = 5 x 7: no skipped pass) instead of 4.  A pure store stream of this shape reaches
-// 6.4-6.6 TB/s on the chip (tools/ubench/store_stream.hip, profiles/r06); the kernel stood at 3.97.
-constexpr int D4_TR = 7, D4_PATCH = 256;           // rows per tile; floats per patch buffer ((D4_TR + 3) x 19 = 190 at stride 1)
+// The 4x4 stride-1 case (resblock1_1_conv1: 7,035 pixels per frame-window; a pure HBM writer -- 6.7 GB per pass of 3,776
+// frames against 0.1 GB read): persistent blocks, the thread's 16 x 4 weights live in registers, a block takes a strip
+// of D4_TR rows x 16 output pixels at a time from its zero-padded input patch in LDS; a pass = one image row of the
+// strip = 16 LDS values + 64 FMAs (32 v_pk_fma_f32) per 16-byte store, the rows the next pass shares stay in registers.
+// Same taps in the same order as the generic kernel (a padded tap adds 0 * w): bitwise the same.
+//
+// Round 6.  (i) The input is read where it lies: `win` makes frame b's 35 x 201 image a sliding window of the
+// log-magnitude spectrogram (SN/apply.py:378's strided_crop is never materialised: the gather_windows kernel and its
+// 104 MB per pass are gone).  (ii) What held this kernel at 3.97 TB/s where a pure store stream of its shape reaches
+// 6.4-6.6 (tools/ubench/store_stream.hip, profiles/r06) was neither bytes nor arithmetic: on gfx9 loads and stores
+// share ONE counter (vmcnt) and complete out of order with respect to each other, so the compiler has to wait for
+// vmcnt(0) -- every store of the wave acknowledged by the L2 -- before it may use ANY global load issued while stores
+// are in flight.  The old kernel loaded two position-table rows per pass: one full write round trip per 16 bytes
+// stored per lane.  Now nothing is loaded from global memory inside a strip: the time term of the table sits in LDS
+// (35 x 64 floats, staged once per block), the frequency term and the clip's bias are fetched once per strip BEFORE its
+// first store, and the next strip's patch is prefetched there too and parked in the other LDS buffer at the strip's
+// end -- the stores drain once per 35 passes instead of once per pass.
+constexpr int D4_TR = 35, D4_PW = 19, D4_PH = D4_TR + 3, D4_NPE = (D4_PH * D4_PW + 255) / 256, D4_PATCH = D4_NPE * 256;
+constexpr int D4_U = 5;                             // passes unrolled together (35 = 7 x 5)
+static_assert(D4_TR % D4_U == 0, "whole groups of passes");
 template <int SPLIT>
 __global__ void __launch_bounds__(256) direct_conv64_4x4(const DirectArgs a, int tiles_r, int tiles_c, int ntiles) {
     __shared__ float patch[2][D4_PATCH];
+    __shared__ __attribute__((aligned(16))) float ttl[D4_TR * 64];
     const int cq = threadIdx.x & 15, c = cq * 4, pc = threadIdx.x >> 4;
     float4 w[16];
 #pragma unroll
     for (int t = 0; t < 16; ++t) w[t] = *reinterpret_cast<const float4*>(a.w + t * 64 + c);
-    const int PH = (D4_TR - 1) * a.sh + 4, PW = 15 * a.sw + 4;
     const int tpi = tiles_r * tiles_c;
-    const int pi_h = (int)threadIdx.x / PW, pi_w = (int)threadIdx.x - pi_h * PW;     // this thread's patch element
-    const bool pi_ok = (int)threadIdx.x < PH * PW;
-    // element `threadIdx.x` of tile `tile`'s patch (0.0: padding, a row outside the clip, no such tile)
-    auto fetch = [&](int tile) -> float {
-        if (tile >= ntiles || !pi_ok) return 0.f;
+    // element e of tile `tile`'s patch (0.0: padding, a row outside the clip, no such tile)
+    auto fetch = [&](int tile, int e) -> float {
+        if (tile >= ntiles || e >= D4_PH * D4_PW) return 0.f;
+        const int pi_h = e / D4_PW, pi_w = e - pi_h * D4_PW;
         const int b = tile / tpi, q = tile - b * tpi;
         const int tr = q / tiles_c;
-        const int hi = tr * D4_TR * a.sh - a.pt + pi_h, wi = (q - tr * tiles_c) * 16 * a.sw - a.pl + pi_w;
+        const int hi = tr * D4_TR - a.pt + pi_h, wi = (q - tr * tiles_c) * 16 - a.pl + pi_w;
         if ((unsigned)hi >= (unsigned)a.H || (unsigned)wi >= (unsigned)a.W) return 0.f;
         if (a.win.t) return win_row_ok(a.win, b, hi) ? a.src[((ptrdiff_t)a.win.row0 + b + hi) * a.W + wi] : 0.f;
         return a.src[((size_t)b * a.H + hi) * a.W + wi];
     };
+    // the table's time term for the rows of a strip, per strip row: tiles_r == 1 (Ho <= 35, every launch there is) keeps it
+    // for the whole kernel; a taller image restages it per strip (launcher: tt_static)
+    const bool tt_static = a.tt && tiles_r == 1;
+    if (tt_static)
+        for (int i = threadIdx.x; i < a.Ho * 64; i += 256) ttl[i] = a.tt[i];
+    const int out_step = a.Wo * 64;
     int cur = 0;
-    patch[0][threadIdx.x] = fetch(blockIdx.x);
+#pragma unroll
+    for (int k = 0; k < D4_NPE; ++k) patch[0][k * 256 + threadIdx.x] = fetch(blockIdx.x, k * 256 + (int)threadIdx.x);
     __syncthreads();
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const float nxt = fetch(tile + gridDim.x);             // in flight under this tile's arithmetic
+        // every global load of this strip AND the next strip's patch: issued here, before the strip's first store
+        float nxt[D4_NPE];
+#pragma unroll
+        for (int k = 0; k < D4_NPE; ++k) nxt[k] = fetch(tile + gridDim.x, k * 256 + (int)threadIdx.x);
         const int b = tile / tpi;
         const int q = tile - b * tpi;
         const int tr = q / tiles_c;
-        const int ho0 = tr * D4_TR, wo0 = (q - tr * tiles_c) * 16;
+        const int ho0 = tr * D4_TR, wo = (q - tr * tiles_c) * 16 + pc;
+        const int npass = a.Ho - ho0 < D4_TR ? a.Ho - ho0 : D4_TR;
+        const bool live = wo < a.Wo;
+        const int wo_c = live ? wo : 0;
         const int clip = a.img_clip ? a.img_clip[b] : 0;
+        float4 cb_, fq_;
         const float4 cb = *reinterpret_cast<const float4*>(a.cb + (size_t)clip * a.cb_stride + c);
-        const float* const pbuf = patch[cur];
+        const float4 fq = a.tt ? *reinterpret_cast<const float4*>(a.ff + wo_c * 64 + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        // (the compiler waits for these two loads HERE -- in front of the strip's first store, with only the previous
+        // strip's last stores to drain -- and the loop below sees registers no load is pending on)
+        {
+            float4 cbv = cb, fqv = fq;
+            asm volatile("" : "+v"(cbv.x), "+v"(cbv.y), "+v"(cbv.z), "+v"(cbv.w), "+v"(fqv.x), "+v"(fqv.y), "+v"(fqv.z), "+v"(fqv.w));
+            cb_ = cbv; fq_ = fqv;
+        }
+        if (a.tt && !tt_static) {
+            __syncthreads();
+            for (int i = threadIdx.x; i < npass * 64; i += 256) ttl[i] = a.tt[ho0 * 64 + i];
+            __syncthreads();
+        }
+        if (live) {
+            const int rem0 = ho0 * a.Wo + wo;
+            float* op = a.out + ((size_t)b * a.Ho * a.Wo + rem0) * 64 + c;
+            const float* tfp = (!a.tt && a.tf) ? a.tf + (size_t)rem0 * 64 + c : nullptr;    // (unsplit table: a global load per pass, the slow way)
+            const float* const px = patch[cur] + pc;
 #pragma unroll 1
-        for (int pass = 0; pass < D4_TR; ++pass) {
-            const int ho = ho0 + pass, wo = wo0 + pc;
-            if (ho >= a.Ho || wo >= a.Wo) continue;
-            const float* px = pbuf + (pass * a.sh) * PW + pc * a.sw;
-            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int p0 = 0; p0 < D4_TR; p0 += D4_U) {
+                if (p0 >= npass) break;
 #pragma unroll
-            for (int t = 0; t < 16; ++t) {
-                const float x = px[(t >> 2) * PW + (t & 3)];
-                acc.x = fmaf(x, w[t].x, acc.x); acc.y = fmaf(x, w[t].y, acc.y);
-                acc.z = fmaf(x, w[t].z, acc.z); acc.w = fmaf(x, w[t].w, acc.w);
-            }
-            const int rem = ho * a.Wo + wo;
-            const size_t m = (size_t)b * a.Ho * a.Wo + rem;
-            acc.x += cb.x; acc.y += cb.y; acc.z += cb.z; acc.w += cb.w;
-            if (a.tt) {
-                const float4 t = *reinterpret_cast<const float4*>(a.tt + ho * 64 + c);
-                const float4 f = *reinterpret_cast<const float4*>(a.ff + wo * 64 + c);
-                acc.x = (acc.x + t.x) + f.x; acc.y = (acc.y + t.y) + f.y; acc.z = (acc.z + t.z) + f.z; acc.w = (acc.w + t.w) + f.w;
-            } else if (a.tf) {
-                const float4 t = *reinterpret_cast<const float4*>(a.tf + (size_t)rem * 64 + c);
-                acc.x += t.x; acc.y += t.y; acc.z += t.z; acc.w += t.w;
-            }
-            if (a.relu) {
-                acc.x = fmaxf(acc.x, 0.f); acc.y = fmaxf(acc.y, 0.f);
-                acc.z = fmaxf(acc.z, 0.f); acc.w = fmaxf(acc.w, 0.f);
-            }
-            acc.x *= a.out_scale; acc.y *= a.out_scale; acc.z *= a.out_scale; acc.w *= a.out_scale;
-            if constexpr (SPLIT) {
-                typedef _Float16 h4 __attribute__((ext_vector_type(4)));
-                h4 hi, lo;
-                if (split_clamp(acc, a.sat_limit) && a.sat) atomicOr(a.sat, kSatActivation);
-                hi.x = (_Float16)acc.x; hi.y = (_Float16)acc.y; hi.z = (_Float16)acc.z; hi.w = (_Float16)acc.w;
-                lo.x = (_Float16)(acc.x - (float)hi.x); lo.y = (_Float16)(acc.y - (float)hi.y);
-                lo.z = (_Float16)(acc.z - (float)hi.z); lo.w = (_Float16)(acc.w - (float)hi.w);
-                _Float16* line = reinterpret_cast<_Float16*>(a.out + m * 64) + (c >> 5) * 64 + (c & 31);
-                __builtin_nontemporal_store(hi, reinterpret_cast<h4*>(line));
-                __builtin_nontemporal_store(lo, reinterpret_cast<h4*>(line + 32));
-            } else {
-                // (f32 storage of a tensor the Winograd kernel reads, or the f32 mode: the same flag and clamp as a split
-                // store -- the reader's transform re-splits what it reads)
-                if (a.sat && split_clamp(acc, a.sat_limit)) atomicOr(a.sat, kSatActivation);
-                {
-                    typedef float fx4 __attribute__((ext_vector_type(4)));
-                    __builtin_nontemporal_store(fx4{acc.x, acc.y, acc.z, acc.w}, reinterpret_cast<fx4*>(a.out + m * 64 + c));
+                for (int u = 0; u < D4_U; ++u) {
+                    const int pass = p0 + u;
+                    if (pass >= npass) break;
+                    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                    for (int t = 0; t < 16; ++t) {
+                        const float x = px[(pass + (t >> 2)) * D4_PW + (t & 3)];
+                        acc.x = fmaf(x, w[t].x, acc.x); acc.y = fmaf(x, w[t].y, acc.y);
+                        acc.z = fmaf(x, w[t].z, acc.z); acc.w = fmaf(x, w[t].w, acc.w);
+                    }
+                    acc.x += cb_.x; acc.y += cb_.y; acc.z += cb_.z; acc.w += cb_.w;
+                    if (a.tt) {
+                        const float4 t = *reinterpret_cast<const float4*>(ttl + pass * 64 + c);
+                        acc.x = (acc.x + t.x) + fq_.x; acc.y = (acc.y + t.y) + fq_.y; acc.z = (acc.z + t.z) + fq_.z; acc.w = (acc.w + t.w) + fq_.w;
+                    } else if (tfp) {
+                        const float4 t = *reinterpret_cast<const float4*>(tfp + (size_t)pass * out_step);
+                        acc.x += t.x; acc.y += t.y; acc.z += t.z; acc.w += t.w;
+                    }
+                    if (a.relu) {
+                        acc.x = fmaxf(acc.x, 0.f); acc.y = fmaxf(acc.y, 0.f);
+                        acc.z = fmaxf(acc.z, 0.f); acc.w = fmaxf(acc.w, 0.f);
+                    }
+                    acc.x *= a.out_scale; acc.y *= a.out_scale; acc.z *= a.out_scale; acc.w *= a.out_scale;
+                    if constexpr (SPLIT) {
+                        typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+                        h4 hi, lo;
+                        if (split_clamp(acc, a.sat_limit) && a.sat) atomicOr(a.sat, kSatActivation);
+                        hi.x = (_Float16)acc.x; hi.y = (_Float16)acc.y; hi.z = (_Float16)acc.z; hi.w = (_Float16)acc.w;
+                        lo.x = (_Float16)(acc.x - (float)hi.x); lo.y = (_Float16)(acc.y - (float)hi.y);
+                        lo.z = (_Float16)(acc.z - (float)hi.z); lo.w = (_Float16)(acc.w - (float)hi.w);
+                        _Float16* line = reinterpret_cast<_Float16*>(op - c) + (c >> 5) * 64 + (c & 31);
+                        __builtin_nontemporal_store(hi, reinterpret_cast<h4*>(line));
+                        __builtin_nontemporal_store(lo, reinterpret_cast<h4*>(line + 32));
+                    } else {
+                        // (f32 storage of a tensor the Winograd kernel reads, or the f32 mode: the same flag and clamp as
+                        // a split store -- the reader's transform re-splits what it reads)
+                        if (a.sat && split_clamp(acc, a.sat_limit)) atomicOr(a.sat, kSatActivation);
+                        typedef float fx4 __attribute__((ext_vector_type(4)));
+                        __builtin_nontemporal_store(fx4{acc.x, acc.y, acc.z, acc.w}, reinterpret_cast<fx4*>(op));
+                    }
+                    op += out_step;
                 }
             }
         }
-        // the next tile's patch into the other buffer: its last readers passed the barrier at the end of the previous turn
-        patch[cur ^ 1][threadIdx.x] = nxt;
+        // the next strip's patch into the other buffer: its last readers passed the barrier at the end of the previous turn
+#pragma unroll
+        for (int k = 0; k < D4_NPE; ++k) patch[cur ^ 1][k * 256 + threadIdx.x] = nxt[k];
         __syncthreads();
         cur ^= 1;
     }
@@ -239,8 +278,7 @@ void launch_absmax(const float* x, size_t nwords, int split, float scale, unsign
 }
 
 void launch_direct_conv64(const DirectArgs& a, hipStream_t s) {
-    const int ph4 = (D4_TR - 1) * a.sh + 4, pw4 = 15 * a.sw + 4;
-    if (a.KH == 4 && a.KW == 4 && ph4 * pw4 <= D4_PATCH && a.M % (a.Ho * a.Wo) == 0) {
+    if (a.KH == 4 && a.KW == 4 && a.sh == 1 && a.sw == 1 && a.M % (a.Ho * a.Wo) == 0) {
         const int tiles_r = (a.Ho + D4_TR - 1) / D4_TR, tiles_c = (a.Wo + 15) / 16;
         const int ntiles = (a.M / (a.Ho * a.Wo)) * tiles_r * tiles_c;
         const int grid4 = ntiles < 256 * 8 ? ntiles : 256 * 8;

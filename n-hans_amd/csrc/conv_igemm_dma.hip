@@ -460,6 +460,26 @@ __global__ void __launch_bounds__(512) conv_igemm_dma(const ConvArgs a) {
         // back AND invalidates it -- issued by all eight waves of every split (7,680 times in the head's dense launch)
         // it kept emptying the L2 under the K loops of the workgroups still running
         // (0.53 -> 0.25 ms for that launch, profiles/r05/ab_splitk_scratch_and_fences.txt).
+        //
+        // Why ONE thread's release and a RELAXED ticket are enough -- by the memory model, not by luck:
+        //  (1) HSA / C++ fence-fence synchronisation: a release fence F_r sequenced before an atomic write X, and an atomic
+        //      read Y that sees X (here: the ticket fetch_add of a later arriver reads the value this one wrote -- RMWs on
+        //      one address form a release sequence) sequenced before an acquire fence F_a, make F_r synchronise with F_a
+        //      whatever the memory order of X and Y themselves: the ticket may be relaxed.  The last arriver's acquire
+        //      fence pairs with EVERY earlier arriver's release fence through the chain of RMWs.
+        //  (2) The other seven waves' stores happen-before thread 0's fence through the workgroup barrier
+        //      (__syncthreads = workgroup-scope release / acquire), and happens-before is transitive across inclusive
+        //      scopes: barrier (workgroup) then fence (agent) publishes them at agent scope.
+        //  (3) What the hardware does for it (CDNA3 ISA, "Memory model" / LLVM AMDGPU memory model for gfx942/gfx950): a
+        //      global store decrements vmcnt when the XCD's L2 has ACKNOWLEDGED the write (the vector L1 is write-through),
+        //      so after `s_waitcnt vmcnt(0)` + s_barrier all eight waves' partials are in this XCD's L2; the agent-scope
+        //      release is `buffer_wbl2 sc1` + `s_waitcnt vmcnt(0)`, which writes back EVERY dirty line of that L2 -- not
+        //      only the issuing wave's -- to memory; the agent-scope RMW executes at the memory side (sc1), coherent across
+        //      XCDs; the acquire is `buffer_inv sc1`, which drops the reader's L2 / L1 copies before it loads the partials
+        //      (with non-temporal loads on top).  The explicit vmcnt(0) in front of the barrier is what (2) needs on this
+        //      hardware: s_barrier alone does not wait for outstanding stores.
+        // tests/test_gpu_abi_edges.py::test_split_k_stress_is_bit_identical_to_the_unsplit_walk runs 10,000 split launches at
+        // the largest grids the rule admits against the unsplit walk, bit for bit.
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (explicit: a workgroup-scope barrier alone need not wait for stores)
         __syncthreads();                                    // every wave's partial stores have reached this XCD's L2
         int* ticket = reinterpret_cast<int*>(smem);

@@ -200,36 +200,92 @@ def check_kernel(name, lines):
     waits = [b for b in blocks if len([l for l in b[2] if l.strip()]) == 1 and re.search(r"s_waitcnt vmcnt\(\d+\)\s*$", b[2][0])]
     if len(consts) < 2:
         errs.append("epilogue: constants request blocks not found")
-    for w in waits:
-        if w[0] < back[1]:
-            continue                                          # (the loop's own waits)
-        prev = [c for c in consts if c[1] < w[0] and w[0] - c[1] <= 600]
-        # (only the blocks of THIS pass: those behind the previous epilogue wait)
-        before = [x for x in waits if back[1] < x[0] < w[0]]
-        if before:
-            prev = [c for c in prev if c[0] > before[-1][1]]
-        if not prev:
+    # Walked along the CONTROL FLOW, not down the text (round 6: with several epilogue instantiations in one kernel the
+    # compiler lays their blocks out interleaved -- a linear scan from a request to "the next wait" ran through another
+    # instantiation's code): from every constants block, every path is followed through branches and fall-throughs
+    # until it reaches a hand-written wait; on the way no instruction may mention a requested register, a later constants
+    # block may not load into one, and the wait's count must equal the vector-memory instructions issued since the LAST
+    # constants block on that path.
+    labels_all = {m.group(1): i for i, l in enumerate(lines) for m in [re.match(r"^(\.LBB\d+_\d+):", l)] if m}
+    block_at = {b[0]: b for b in blocks}
+    const_at = {c[0] for c in consts}
+    wait_at = {w[0] for w in waits if w[0] > back[1]}
+    VM = re.compile(r"\s*(global_|buffer_|scratch_|flat_)")
+    seen_err = set()
+
+    def err(msg):
+        if msg not in seen_err:
+            seen_err.add(msg)
+            errs.append(msg)
+
+    checked_waits = set()
+    for c in consts:
+        if c[0] < back[1]:
             continue
-        n = int(re.search(r"vmcnt\((\d+)\)", w[2][0]).group(1))
-        # exactly n vector-memory instructions lie between the LAST constants block and the wait ...
-        cnt = 0
-        for i in range(prev[-1][1] + 1, w[0]):
-            code = lines[i].split(";")[0]
-            if re.match(r"\s*(global_|buffer_|scratch_|flat_)", code):
-                cnt += 1
-        if cnt < n or (cnt != n and not dbg):
-            errs.append("epilogue: %d vector-memory instructions between the constants and s_waitcnt vmcnt(%d) (line %d)" % (cnt, n, w[0]))
-        # ... and from EACH constants block to the wait nothing mentions the registers that block writes -- neither the
-        # compiler's own instructions nor a later request block (two loads in flight into one register).  A register whose
-        # value the source never reads is free to the compiler from the asm statement on: round 5's faults.
-        for c in prev:
-            regs = load_regs(c)
-            for i in range(c[1] + 1, w[0]):
-                code = lines[i].split(";")[0]
-                if vgprs(code) & regs:
-                    errs.append("epilogue: a register of the constants request at line %d is touched before the wait (line %d): %s"
-                                % (c[0], i, lines[i].strip()[:80]))
+        # state: (line, tracked registers as a frozenset of (register, request line), count since the last constants block)
+        stack = [(c[1] + 1, frozenset((r, c[0]) for r in load_regs(c)), 0, 0)]
+        seen = set()
+        while stack:
+            i, tracked, cnt, steps = stack.pop()
+            while True:
+                if (i, tracked, cnt) in seen or i >= len(lines):
                     break
+                seen.add((i, tracked, cnt))
+                steps += 1
+                if steps > 4000:
+                    err("epilogue: no counted wait within 4000 instructions of the constants request at line %d" % c[0])
+                    break
+                if i in block_at:
+                    b = block_at[i]
+                    if i in wait_at:
+                        n = int(re.search(r"vmcnt\((\d+)\)", b[2][0]).group(1))
+                        checked_waits.add(i)
+                        if cnt < n or (cnt != n and not dbg):
+                            err("epilogue: %d vector-memory instructions between the constants and s_waitcnt vmcnt(%d) (line %d)" % (cnt, n, i))
+                        break
+                    regs_t = {r for r, _ in tracked}
+                    if i in const_at:
+                        if load_regs(b) & regs_t:
+                            err("epilogue: a register of the constants request at line %d is touched before the wait (line %d): a second request loads into it"
+                                % (c[0], i))
+                            break
+                        tracked = tracked | frozenset((r, i) for r in load_regs(b))
+                        cnt = 0
+                    else:
+                        for l in b[2]:
+                            code = l.split(";")[0]
+                            if vgprs(code) & regs_t:
+                                err("epilogue: a register of the constants request at line %d is touched before the wait (line %d): %s"
+                                    % (c[0], i, l.strip()[:80]))
+                            if VM.match(code):
+                                cnt += 1
+                    i = b[1] + 1
+                    continue
+                code = lines[i].split(";")[0]
+                t = code.strip()
+                if not t or t.startswith((".", "#")) or t.endswith(":"):
+                    i += 1
+                    continue
+                hit = vgprs(code) & {r for r, _ in tracked}
+                if hit:
+                    origin = sorted({o for r, o in tracked if r in hit})[0]
+                    err("epilogue: a register of the constants request at line %d is touched before the wait (line %d): %s"
+                        % (origin, i, t[:80]))
+                    break
+                if VM.match(code):
+                    cnt += 1
+                if t.startswith("s_endpgm"):
+                    err("epilogue: the constants request at line %d reaches the end of the kernel without a counted wait" % c[0])
+                    break
+                m = re.match(r"(s_branch|s_cbranch\w*)\s+(\.LBB\d+_\d+)", t)
+                if m and m.group(2) in labels_all:
+                    if m.group(1) == "s_branch":
+                        i = labels_all[m.group(2)]
+                        continue
+                    stack.append((labels_all[m.group(2)], tracked, cnt, steps))
+                i += 1
+    if consts and not checked_waits:
+        errs.append("epilogue: no counted wait reached from the constants requests")
     inasm = False
     for i in range(first, back[1] + 1):
         l = lines[i]
