@@ -328,29 +328,8 @@ __device__ __forceinline__ void conv_epilogue_sweep8(const ConvArgs& a, const fl
             {
                 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
                 const uint32_t so = valid ? (uint32_t)(r[u].m - mb) * ost + (uint32_t)hoff * 2u : 0x80000000u;
-#ifndef NHANS_EPI_WHOLELINE
-#define NHANS_EPI_WHOLELINE 0
-#endif
-#if NHANS_EPI_WHOLELINE
-                // Whole 128-byte lines per store instruction (round 6 A/B): the 16-lane rows of a wave are pixels; with
-                // v_permlane16_swap_b32 (gfx950) an even row keeps its hi halves and takes the odd row's, the odd row takes the
-                // even row's lo halves and keeps its own -- the first store then writes hi AND lo of the even pixel (8 lanes per
-                // line instead of 4 lanes for half of it), the second those of the odd pixel.  Same bytes to the same addresses.
-                const bool odd_row = (__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) & 16u) != 0;
-                unsigned a4[4] = {hq.x, hq.y, hq.z, hq.w}, b4[4] = {lq.x, lq.y, lq.z, lq.w};
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const auto sw = __builtin_amdgcn_permlane16_swap(a4[e], b4[e], false, false);
-                    a4[e] = sw[0]; b4[e] = sw[1];
-                }
-                const auto so2 = __builtin_amdgcn_permlane16_swap(so, so, false, false);   // [0]: the even pixel's offset, [1]: the odd pixel's
-                const uint32_t half = odd_row ? 64u : 0u;
-                __builtin_amdgcn_raw_buffer_store_b128(u32x4{a4[0], a4[1], a4[2], a4[3]}, orsrc, so2[0] + half, 0, 2);
-                __builtin_amdgcn_raw_buffer_store_b128(u32x4{b4[0], b4[1], b4[2], b4[3]}, orsrc, so2[1] + half, 0, 2);
-#else
                 __builtin_amdgcn_raw_buffer_store_b128(u32x4{hq.x, hq.y, hq.z, hq.w}, orsrc, so, 0, 2);     // (2 = nt: written once)
                 __builtin_amdgcn_raw_buffer_store_b128(u32x4{lq.x, lq.y, lq.z, lq.w}, orsrc, so + 64u, 0, 2);
-#endif
             }
         }
     };

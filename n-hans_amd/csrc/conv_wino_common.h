@@ -202,12 +202,9 @@ __device__ __forceinline__ void wino_epilogue(const ConvArgs& a, const f32x16 (*
     if constexpr (IDM == 1 || IDM == 2) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * RQ0) : "memory");
     else if constexpr (IDM == 3) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(RQ0) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#ifndef NHANS_EPI_TRIM
-#define NHANS_EPI_TRIM 0
-#endif
-    // (NHANS_EPI_TRIM, round 6: the output's power-of-two scale 2^-e rides in the constants -- ws, bias, idw times out_scale
-    // -- instead of one multiply per output element at the end of the sweep; exact, so the same bits)
-    const float osc_c = NHANS_EPI_TRIM ? CONV_KARG(out_scale) : 1.f;
+    // (round 6: the output's power-of-two scale 2^-e rides in the constants -- ws, bias, idw times out_scale -- instead of
+    // one multiply per output element at the end of the sweep; exact, so the same bits)
+    const float osc_c = CONV_KARG(out_scale);
     if (chan_head) {
         if constexpr (IDM != 0) NH_LANDED4(ka[0], ka[1], ka[2], ka[3]); else NH_LANDED2(ka[0], ka[1]);
         const float in_scale = CONV_KARG(in_scale) * osc_c, id_scale = CONV_KARG(id_scale) * osc_c;
@@ -236,32 +233,6 @@ __device__ __forceinline__ void wino_epilogue(const ConvArgs& a, const f32x16 (*
     __builtin_amdgcn_sched_barrier(0);
     float* const my = ct + q * W_LDM + c8 * 4;                                // + position * 64 * W_LDM + (0 | 32)
     static_assert(MO - RQ0 <= 4, "one late residual column per transform iteration");
-#ifndef NHANS_EPI_PIPE
-#define NHANS_EPI_PIPE 0
-#endif
-#if NHANS_EPI_PIPE & 1
-    // Software-pipelined by hand (round 6): the ten LDS reads of iteration qt + 1 are issued BEFORE the arithmetic of
-    // iteration qt (two register sets; the loop is unrolled, the set index is static) -- two in-order waves per SIMD hide
-    // no LDS latency for each other, fenced per iteration every one of the four exposed its own.
-    f32x2 mm[2][8], wsq[2], hcq[2];
-    auto tload = [&](int qt) {
-        float* const slot = my + (qt >> 1) * 32 + (qt & 1) * 2;
-        const int cq = c8 * CHA + (qt >> 1) * CHB + (qt & 1) * 2;
-#pragma unroll
-        for (int pp = 0; pp < 8; ++pp) mm[qt & 1][pp] = *reinterpret_cast<const f32x2*>(slot + pp * 64 * W_LDM);
-        wsq[qt & 1] = *reinterpret_cast<const f32x2*>(cst + cq);
-        hcq[qt & 1] = *reinterpret_cast<const f32x2*>(cst + (2 + (rr < TR ? rr : 0)) * 64 + cq);
-    };
-    tload(0);
-#pragma unroll
-    for (int qt = 0; qt < 4; ++qt) {
-        if (qt + 1 < 4) tload(qt + 1);
-        if (RQ0 + qt < MO) residual(RQ0 + qt);
-        __builtin_amdgcn_sched_barrier(0);
-        float* const slot = my + (qt >> 1) * 32 + (qt & 1) * 2;
-        const f32x2* const m = mm[qt & 1];
-        const f32x2 ws2 = wsq[qt & 1], hc2 = hcq[qt & 1];
-#else
 #pragma unroll
     for (int qt = 0; qt < 4; ++qt) {
         if (RQ0 + qt < MO) residual(RQ0 + qt);
@@ -272,7 +243,6 @@ __device__ __forceinline__ void wino_epilogue(const ConvArgs& a, const f32x16 (*
         const int cq = c8 * CHA + (qt >> 1) * CHB + (qt & 1) * 2;            // the pair's first channel within the block
         const f32x2 ws2 = *reinterpret_cast<const f32x2*>(cst + cq);
         const f32x2 hc2 = *reinterpret_cast<const f32x2*>(cst + (2 + (rr < TR ? rr : 0)) * 64 + cq);
-#endif
         const f32x2 s12 = m[1] + m[2], d12 = m[1] - m[2], s34 = m[3] + m[4], d34 = m[3] - m[4], s56 = m[5] + m[6], d56 = m[5] - m[6];
         f32x2 y[MO];
         y[0] = (m[0] + s12) + (s34 + s56);
@@ -308,27 +278,10 @@ __device__ __forceinline__ void wino_epilogue(const ConvArgs& a, const f32x16 (*
     const uint32_t oo0 = (uint32_t)pix0 * (uint32_t)a.ldo * 4u + (uint32_t)((n_again >> 5) * 64 + (n_again & 31)) * 2u, ost = (uint32_t)a.ldo * 4u;
     const uint32_t oo0f = (uint32_t)pix0 * (uint32_t)a.ldo * 4u + (uint32_t)n_again * 4u;
     int sat = 0;
-#if NHANS_EPI_PIPE & 2
-    // (the same for the sweep: column i + 1's four 16-byte LDS reads go out before column i's arithmetic and stores)
-    f32x4 cy[2][4];
-    auto cload = [&](int i) {
-        cy[i & 1][0] = *reinterpret_cast<const f32x4*>(my + i * 64 * W_LDM);
-        cy[i & 1][1] = *reinterpret_cast<const f32x4*>(my + i * 64 * W_LDM + 32);
-        cy[i & 1][2] = *reinterpret_cast<const f32x4*>(ffc + i * 64);
-        cy[i & 1][3] = *reinterpret_cast<const f32x4*>(ffc + i * 64 + CHB);
-    };
-    cload(0);
-#endif
 #pragma unroll
     for (int i = 0; i < MO; ++i) {
-#if NHANS_EPI_PIPE & 2
-        if (i + 1 < MO) cload(i + 1);
-        __builtin_amdgcn_sched_barrier(0);
-        const f32x4 ya = cy[i & 1][0], yb = cy[i & 1][1], t0 = cy[i & 1][2], t1 = cy[i & 1][3];
-#else
         const f32x4 ya = *reinterpret_cast<const f32x4*>(my + i * 64 * W_LDM);
         const f32x4 yb = *reinterpret_cast<const f32x4*>(my + i * 64 * W_LDM + 32);
-#endif
         f32x4 i0 = {0.f, 0.f, 0.f, 0.f}, i1 = i0;
         if constexpr (IDM == 1) {
             // (float)hi + (float)lo, one v_fma_mix_f32 per value
@@ -341,13 +294,10 @@ __device__ __forceinline__ void wino_epilogue(const ConvArgs& a, const f32x16 (*
             i0 = f32x4{rsv[i], rsv[i], rsv[i], rsv[i]};
             i1 = i0;
         }
-#if !(NHANS_EPI_PIPE & 2)
         const f32x4 t0 = *reinterpret_cast<const f32x4*>(ffc + i * 64), t1 = *reinterpret_cast<const f32x4*>(ffc + i * 64 + CHB);
-#endif
         const bool valid = i < nvalid;
         float yc[8];
         bool over = false;
-#if NHANS_EPI_TRIM
         // ya / yb / iw carry out_scale already (exact: a power of two); the table term joins by one fma.  The saturation test is
         // ONE compare on the largest magnitude of the thread's eight values (a NaN cannot arrive here as a NaN: fmaxf with the
         // relu floor -- or with -3e38 -- has replaced it), and the clamp runs only in a wave that has something to clamp: below
@@ -368,16 +318,6 @@ __device__ __forceinline__ void wino_epilogue(const ConvArgs& a, const f32x16 (*
 #pragma unroll
             for (int e = 0; e < 8; ++e) yc[e] = __builtin_amdgcn_fmed3f(yc[e], -65504.f, 65504.f);
         }
-#else
-        const f32x4 r0v = fma4(iw0, i0, ya + t0);              // (= epi_combine: ya already is fma(acc, ws, bias))
-        const f32x4 r1v = fma4(iw1, i1, yb + t1);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const float v = fmaxf(e < 4 ? r0v[e] : r1v[e - 4], lo_clamp) * osc;
-            over |= !(fabsf(v) < slim);
-            yc[e] = __builtin_amdgcn_fmed3f(v, -65504.f, 65504.f);
-        }
-#endif
         sat |= (over && valid) ? 1 : 0;
         asm volatile("" : "+v"(sat));                       // (here, not after the loop: the compiler would keep all 8*MO values alive for it)
         // The two stores of a column are UNCONDITIONAL buffer stores (an invalid column's offset lies beyond the frame: the
