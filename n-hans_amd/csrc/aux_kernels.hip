@@ -29,13 +29,12 @@ __global__ void __launch_bounds__(256) direct_conv64(const DirectArgs a) {
         const uint32_t rem = (uint32_t)m - b * a.fdHoWo.d;
         const uint32_t ho = fd_div(rem, a.fdWo);
         const uint32_t wo = rem - ho * a.fdWo.d;
-        const float* img = a.win.t ? a.src + ((ptrdiff_t)a.win.row0 + (ptrdiff_t)b) * a.W : a.src + (size_t)b * a.H * a.W;
+        const float* img = a.src + (size_t)b * a.H * a.W;
         const int hi0 = (int)ho * a.sh - a.pt, wi0 = (int)wo * a.sw - a.pl;
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
         for (int kh = 0; kh < a.KH; ++kh) {
             const int hi = hi0 + kh;
             if ((unsigned)hi >= (unsigned)a.H) continue;
-            if (a.win.t && !win_row_ok(a.win, (int)b, hi)) continue;      // (a zero row adds 0 * w: skipped like padding)
             for (int kw = 0; kw < a.KW; ++kw) {
                 const int wi = wi0 + kw;
                 if ((unsigned)wi >= (unsigned)a.W) continue;
@@ -118,10 +117,8 @@ __global__ void __launch_bounds__(256) direct_conv64_4x4(const DirectArgs a, int
         if (a.win.t) return win_row_ok(a.win, b, hi) ? a.src[((ptrdiff_t)a.win.row0 + b + hi) * a.W + wi] : 0.f;
         return a.src[((size_t)b * a.H + hi) * a.W + wi];
     };
-    // the table's time term for the rows of a strip, per strip row: tiles_r == 1 (Ho <= 35, every launch there is) keeps it
-    // for the whole kernel; a taller image restages it per strip (launcher: tt_static)
-    const bool tt_static = a.tt && tiles_r == 1;
-    if (tt_static)
+    // the table's time term for the rows of the strip (the launcher admits Ho <= D4_TR: one strip per image column block)
+    if (a.tt)
         for (int i = threadIdx.x; i < a.Ho * 64; i += 256) ttl[i] = a.tt[i];
     const int out_step = a.Wo * 64;
     int cur = 0;
@@ -150,11 +147,6 @@ __global__ void __launch_bounds__(256) direct_conv64_4x4(const DirectArgs a, int
             float4 cbv = cb, fqv = fq;
             asm volatile("" : "+v"(cbv.x), "+v"(cbv.y), "+v"(cbv.z), "+v"(cbv.w), "+v"(fqv.x), "+v"(fqv.y), "+v"(fqv.z), "+v"(fqv.w));
             cb_ = cbv; fq_ = fqv;
-        }
-        if (a.tt && !tt_static) {
-            __syncthreads();
-            for (int i = threadIdx.x; i < npass * 64; i += 256) ttl[i] = a.tt[ho0 * 64 + i];
-            __syncthreads();
         }
         if (live) {
             const int rem0 = ho0 * a.Wo + wo;
@@ -278,12 +270,16 @@ void launch_absmax(const float* x, size_t nwords, int split, float scale, unsign
 }
 
 void launch_direct_conv64(const DirectArgs& a, hipStream_t s) {
-    if (a.KH == 4 && a.KW == 4 && a.sh == 1 && a.sw == 1 && a.M % (a.Ho * a.Wo) == 0) {
+    if (a.KH == 4 && a.KW == 4 && a.sh == 1 && a.sw == 1 && a.Ho <= D4_TR && a.M % (a.Ho * a.Wo) == 0) {
         const int tiles_r = (a.Ho + D4_TR - 1) / D4_TR, tiles_c = (a.Wo + 15) / 16;
         const int ntiles = (a.M / (a.Ho * a.Wo)) * tiles_r * tiles_c;
         const int grid4 = ntiles < 256 * 8 ? ntiles : 256 * 8;
         if (a.out_split) NHANS_LAUNCH("direct_conv64_4x4", direct_conv64_4x4<1>, dim3(grid4), dim3(256), 0, s, a, tiles_r, tiles_c, ntiles);
         else NHANS_LAUNCH("direct_conv64_4x4", direct_conv64_4x4<0>, dim3(grid4), dim3(256), 0, s, a, tiles_r, tiles_c, ntiles);
+        return;
+    }
+    if (a.win.t) {                  // (sliding-window images are read by the 4x4 stride-1 kernel only: the one first conv that has them)
+        note_refusal("direct_conv64 (sliding-window input with a filter the 4x4 kernel does not take)");
         return;
     }
     int grid = (a.M + 15) / 16;

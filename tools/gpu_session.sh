@@ -1,7 +1,7 @@
 #!/bin/bash
 # One GPU-box session: GPU test suite, the headline bench line, rocprofv3 kernel stats of the same
 # command.  Usage (from the repo root, through gpurun):  bash tools/gpu_session.sh <tag> [what...]
-#   what: tests bench bench1 prof pmc benchq dist1  (default: tests bench prof)
+#   what: tests bench bench1 prof pmc benchq dist1 cli cold soak fuzz recipes driver  (default: tests bench prof)
 set -u
 TAG=${1:-s}; shift || true
 WHAT=${*:-tests bench prof}
@@ -47,4 +47,22 @@ if has dist1; then
   # and its RCCL leg with the one rank a one-GPU box allows (communicator init, all-gather, barriers, all-reduce)
   timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29533 \
       bench.py --gpus 1 --steps 2 --warmup 1 --clips-per-gpu 16 --force-dist --no-cpu-baseline > $OUT/bench_rccl_1rank.json 2> $OUT/bench_rccl_1rank.err; echo "rccl1 rc=$?"
+fi
+if has cli; then      # files in -> files out through the command line, 256 wavs (first call and steady state)
+  timeout 900 python tools/cli_e2e.py 256 10 > $OUT/cli_e2e_256clips.log 2>&1; tail -c 1200 $OUT/cli_e2e_256clips.log
+fi
+if has cold; then     # one 10 s file per fresh process: configs[1] as a user meets it
+  timeout 600 python tools/cold_call.py 3 10 > $OUT/cold_call.json 2>$OUT/cold_call.err; grep -A6 summary_wall_s $OUT/cold_call.json
+fi
+if has soak; then
+  timeout 900 python tools/soak.py 60 4 > $OUT/soak.log 2>&1; tail -3 $OUT/soak.log
+fi
+if has fuzz; then
+  timeout 1200 python tools/fuzz_batches.py 150 > $OUT/fuzz_batches.log 2>&1; tail -3 $OUT/fuzz_batches.log
+fi
+if has recipes; then  # the parity tables with their absolute errors printed
+  timeout 900 python -m pytest tests/test_gpu_recipes.py tests/test_gpu_full10s.py -m gpu -q -s > $OUT/pytest_gpu_recipes_full10s.log 2>&1; tail -2 $OUT/pytest_gpu_recipes_full10s.log
+fi
+if has driver; then   # the driver's own command
+  timeout 600 python bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/bench_256clips_driver_shape_20steps.json 2>$OUT/bench_driver_shape.err; tail -c 600 $OUT/bench_256clips_driver_shape_20steps.json
 fi
