@@ -78,7 +78,9 @@ def test_full_ten_second_clip_logits_and_waveform(kind_eng, prec, wino):
         assert err.max() < LOGIT_TOL
         assert np.abs(den.cpu().numpy() - (small["logmag"] + full["logits"])).max() < LOGIT_TOL
         assert rms < WAV_RMS_TOL
-        assert e2e < 5 * LOGIT_TOL                      # (the float32 STFT moves log(|X|+1e-5) at silent bins: DESIGN.md section 2)
+        # from the WAVEFORM the float32 STFT moves log(|X|+1e-5) at silent bins (the short-clip tests allow
+        # 5e-4 for it); on the metric's own clips the literal bar holds: 1.5e-5 (denoiser) / 8.6e-5 (separator)
+        assert e2e < LOGIT_TOL
     finally:
         eng.set_option("winograd", 1)
 
