@@ -64,7 +64,8 @@ def parse(argv=None):
     p.add_argument("--ceiling-seconds", type=float, default=2.0,
                    help="length of the register-only f16 MFMA run that measures this box's rate at its power cap")
     p.add_argument("--no-ceiling", action="store_true", help="skip that measurement (peak_at_power_cap is then null: no constant stands in)")
-    p.add_argument("--cpu-frames", type=int, default=32, help="frames of the CPU baseline sample")
+    p.add_argument("--cpu-frames", type=int, default=100,
+                   help="frames of the CPU baseline sample: one minibatch of the reference's own size (SN/apply.py:398-450: 100), 10-15 s of CPU work")
     p.add_argument("--cpu-threads", type=int, default=0, help="0 = min(host cores, 64)")
     p.add_argument("--force-dist", action="store_true",
                    help="initialise the process group and run the all-gather and barriers even at world size 1 "
@@ -432,7 +433,14 @@ def main(argv=None):
         # the one it was collected on AND the kernel sources are the ones it was collected from (the summary carries a
         # fingerprint of n-hans_amd/csrc + fold.py, tools/pmc_summary.py): a kernel change makes `traffic` null instead of
         # silently stale
-        traffic, traffic_src = None, None
+        traffic, traffic_src, dom_traffic = None, None, None
+        # the DOMINANT kernel of the step (most milliseconds among the conv launches): what `roofline`'s own fields describe;
+        # the aggregate over all conv launches stands beside it as `all_conv_launches`
+        dom = max(convs, key=lambda k: convs[k]["ms"]) if convs else None
+        # bench label -> does a PMC-summary kernel name belong to it
+        pmc_match = {"conv_wino<128>": lambda n: "conv_wino<" in n,
+                     "conv_igemm_halo<128>": lambda n: "conv_igemm_halo<128" in n and n.rstrip().endswith(", 0>"),
+                     "conv_igemm_halo_pw<128>": lambda n: "conv_igemm_halo<128" in n and n.rstrip().endswith(", 1>")}
         import glob
         pmcs = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9]*", PMC_SUMMARY_NAME)), reverse=True)
         if a.precision == "f16x3" and a.clips_per_gpu == 256 and a.seconds == 10.0 and a.kind == "denoiser" and pmcs:
@@ -449,18 +457,23 @@ def main(argv=None):
             if summary is None:
                 traffic_src = "%s (the newest PMC summary) is of other kernel sources: not quoted" % PMC_SUMMARY
             else:
+                per_launch = lambda rows: (sum((v.get("derived_hbm_read_bytes_per_launch", 0.0) + v.get("derived_hbm_write_bytes_per_launch", 0.0))
+                                               * v.get("dispatches_pass_c", 0) for v in rows) / max(1, sum(v.get("dispatches_pass_c", 0) for v in rows)))
                 rows = [v for k, v in summary.items() if "conv_igemm" in k or "conv_wino" in k]
-                n = sum(v.get("dispatches_pass_c", 0) for v in rows)
-                if n:
-                    traffic = sum((v.get("derived_hbm_read_bytes_per_launch", 0.0) + v.get("derived_hbm_write_bytes_per_launch", 0.0))
-                                  * v.get("dispatches_pass_c", 0) for v in rows) / n
-                    traffic_src = "%s (FETCH_SIZE x2 + WRITE_SIZE, bytes per conv launch; commit %s)" % (PMC_SUMMARY, meta.get("commit"))
+                if sum(v.get("dispatches_pass_c", 0) for v in rows):
+                    traffic = per_launch(rows)
+                    traffic_src = "%s (FETCH_SIZE x2 + WRITE_SIZE, bytes per launch; commit %s)" % (PMC_SUMMARY, meta.get("commit"))
+                drows = [v for k, v in summary.items() if dom in pmc_match and pmc_match[dom](k)]
+                if sum(v.get("dispatches_pass_c", 0) for v in drows):
+                    dom_traffic = per_launch(drows)
         gbs = lambda e: e["bytes"] / (e["ms"] * 1e-3) / 1e9 if e and e["ms"] > 0 else None
         # stft_features = the mixture's STFT (log-magnitude + phase: the 2,248 B/frame of SURVEY 8d); the two
         # context STFTs (200 frames per clip, log-magnitude only: 1,444 B/frame) are timed as their own entry
         stft_gbs, istft_gbs = gbs(prof.get("stft_features")), gbs(prof.get("istft_ola"))
         stft_ctx_gbs = gbs(prof.get("stft_context_features"))
         step_flops = conv_fl + sum(v["flops"] for k, v in prof.items() if k.startswith("direct_conv"))
+        dtf = lambda k: convs[k]["flops"] / (convs[k]["ms"] * 1e-3) / 1e12 if k and convs[k]["ms"] > 0 else None
+        dexec = lambda k: convs[k].get("mfma_flops", 0.0) / (convs[k]["ms"] * 1e-3) / 1e12 if k and convs[k]["ms"] > 0 else None
         line = {
             "metric": "denoised audio seconds per second (16 kHz), whole job",
             "value": world * audio_s * a.steps / dt,
@@ -485,20 +498,28 @@ def main(argv=None):
             "rccl_ranks": rccl_ranks,
             # accuracy of the measured output itself: the golden 10 s clip is part of the timed batch
             "rms_vs_golden_10s": golden_rms,
-            "roofline": {"bound": "mfma", "kernel": "conv_igemm_* + conv_wino (all implicit-GEMM / Winograd conv launches of a step)",
-                         "achieved_basis": "algorithmic FLOPs of the DIRECT convolutions (2*M*K*N), whichever form runs them",
-                         "achieved": tflops, "peak": peak, "unit": "TFLOP/s", "frac": tflops / peak,
-                         "traffic": traffic, "traffic_source": traffic_src,
-                         "launches": conv_calls, "kernel_ms_per_step": conv_ms,
-                         "avg_launch_ms": conv_ms / conv_calls if conv_calls else None,
-                         "algorithmic_gflop_per_launch": conv_fl / conv_calls / 1e9 if conv_calls else None,
-                         "executed_tflops": exec_tflops,
-                         "executed_frac": exec_tflops / peak,
+            "roofline": {"bound": "mfma", "kernel": dom,
+                         "kernel_share_of_step": (convs[dom]["ms"] / ms_step) if dom else None,
+                         "achieved_basis": "ALGORITHMIC FLOPs of the direct convolutions this kernel's launches stand for (2*M*K*N per "
+                                           "launch, whichever form runs them) / the launches' summed duration",
+                         "achieved": dtf(dom), "peak": peak, "unit": "TFLOP/s", "frac": (dtf(dom) or 0.0) / peak,
+                         "traffic": dom_traffic, "traffic_source": traffic_src,
+                         "launches": convs[dom]["calls"] if dom else 0, "kernel_ms_per_step": convs[dom]["ms"] if dom else None,
+                         "avg_launch_ms": convs[dom]["ms"] / convs[dom]["calls"] if dom else None,
+                         "algorithmic_gflop_per_launch": convs[dom]["flops"] / convs[dom]["calls"] / 1e9 if dom else None,
+                         "executed_tflops": dexec(dom),
+                         "executed_frac": (dexec(dom) or 0.0) / peak,
+                         # every implicit-GEMM / Winograd conv launch of a step together (97 % of the step)
+                         "all_conv_launches": {"achieved": tflops, "frac": tflops / peak, "traffic": traffic, "launches": conv_calls,
+                                               "kernel_ms_per_step": conv_ms, "avg_launch_ms": conv_ms / conv_calls if conv_calls else None,
+                                               "algorithmic_gflop_per_launch": conv_fl / conv_calls / 1e9 if conv_calls else None,
+                                               "executed_tflops": exec_tflops, "executed_frac": exec_tflops / peak,
+                                               "executed_frac_of_peak_at_power_cap": exec_tflops / cap_tf if cap_tf else None},
                          # what back-to-back f16 MFMAs on random register operands sustain at the socket power cap
                          # (tools/ubench/mfma_power.hip, profiles/r02/mfma_power_ceiling.txt); the datasheet peak is
                          # reached with all-zero operands only
                          "peak_at_power_cap": cap_tf,
-                         "executed_frac_of_peak_at_power_cap": exec_tflops / cap_tf if cap_tf else None,
+                         "executed_frac_of_peak_at_power_cap": (dexec(dom) or 0.0) / cap_tf if cap_tf else None,
                          "peak_at_power_cap_source": ("measured in this run on this device: %.1f s of back-to-back "
                                                       "v_mfma_f32_32x32x16_f16 on random register operands after the timed "
                                                       "region (nhans_debug_mfma_ceiling)" % a.ceiling_seconds) if ceiling
