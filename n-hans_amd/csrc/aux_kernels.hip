@@ -86,11 +86,11 @@ __global__ void __launch_bounds__(256) direct_conv64(const DirectArgs a) {
 // Round 6.  (i) The input is read where it lies: `win` makes frame b's 35 x 201 image a sliding window of the
 // log-magnitude spectrogram (SN/apply.py:378's strided_crop is never materialised: the gather_windows kernel and its
 // 104 MB per pass are gone).  (ii) What held this kernel at 3.97 TB/s where a pure store stream of its shape reaches
-// 6.4-6.6 (tools/ubench/store_stream.hip, profiles/r06) was neither bytes nor arithmetic: on gfx9 loads and stores
-// share ONE counter (vmcnt) and complete out of order with respect to each other, so the compiler has to wait for
-// vmcnt(0) -- every store of the wave acknowledged by the L2 -- before it may use ANY global load issued while stores
-// are in flight.  The old kernel loaded two position-table rows per pass: one full write round trip per 16 bytes
-// stored per lane.  Now nothing is loaded from global memory inside a strip: the time term of the table sits in LDS
+// 6.4-6.6 (tools/ubench/store_stream.hip, profiles/r06) was neither bytes nor arithmetic: on gfx9 a wave's loads and
+// stores retire through ONE in-order counter (vmcnt) -- a load issued behind a store cannot be waited for without that
+// store's acknowledgement from the L2 as well -- and inside a loop, where the compiler cannot count the stores in
+// flight, every wait for a load becomes vmcnt(0).  The old kernel loaded two position-table rows per pass: one full
+// write round trip per 16 bytes stored per lane.  Now nothing is loaded from global memory inside a strip: the time term of the table sits in LDS
 // (35 x 64 floats, staged once per block), the frequency term and the clip's bias are fetched once per strip BEFORE its
 // first store, and the next strip's patch is prefetched there too and parked in the other LDS buffer at the strip's
 // end -- the stores drain once per 35 passes instead of once per pass.

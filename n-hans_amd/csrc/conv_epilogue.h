@@ -168,7 +168,7 @@ __device__ __forceinline__ void conv_epilogue_sweep(const ConvArgs& a, const flo
             } else if constexpr (IDM == 2) {
                 idv = *reinterpret_cast<const f32x4*>(a.id + (size_t)mc * a.id_ld + n);
             } else if constexpr (IDM == 3) {
-                const float sv = *(ri.w >= 0 ? a.id + ri.w : a.zero);      // (address select: the load stays unconditional)
+                const float sv = *(ri.w != kNoRow ? a.id + ri.w : a.zero);      // (address select: the load stays unconditional)
                 idv = f32x4{sv, sv, sv, sv};
             }
             const f32x4 y = epi_combine(av, wsv, c, t, idwv, idv);
@@ -277,7 +277,7 @@ __device__ __forceinline__ void conv_epilogue_sweep8(const ConvArgs& a, const fl
                 r[u].h = __builtin_nontemporal_load(reinterpret_cast<const f16x8*>(hp));     // (read once: keep the L2 for
                 r[u].l = __builtin_nontemporal_load(reinterpret_cast<const f16x8*>(hp + 32)); //  weights, tables and halos)
             } else if constexpr (IDM == 3) {
-                r[u].sv = *(ri.w >= 0 ? a.id + ri.w : a.zero);
+                r[u].sv = *(ri.w != kNoRow ? a.id + ri.w : a.zero);
             }
         }
     };
@@ -388,11 +388,13 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[T
         const uint32_t ho = fd_div(rem, a.fdWo);
         const uint32_t wo = rem - ho * a.fdWo.d;
         const int clip = a.img_clip ? a.img_clip[b] : 0;
-        // (1-channel residual image: element index into a.id, or -1 = a zero row of a sliding-window image, WinRows)
+        // (1-channel residual image: element index into a.id, or kNoRow = a zero row of a sliding-window image, WinRows; a
+        // window's rows are counted from the launch's first frame, so a VALID index may be negative: the rows of a clip that
+        // began before this chunk of frames)
         int ids;
         if (a.id_mode == 2 && a.id_win.t) {
             const int h = (int)ho * a.idsh;
-            ids = win_row_ok(a.id_win, (int)b, h) ? (a.id_win.row0 + (int)b + h) * a.idW + (int)wo * a.idsw : -1;
+            ids = win_row_ok(a.id_win, (int)b, h) ? (a.id_win.row0 + (int)b + h) * a.idW + (int)wo * a.idsw : kNoRow;
         } else {
             ids = (int)((b * a.idH + ho * a.idsh) * a.idW + wo * a.idsw);
         }
@@ -450,7 +452,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[T
             const int4 ri = rowinfo[p];
             const int m = ri.z;
             if (m < 0) continue;
-            const float idsv = a.id_mode == 2 && ri.w >= 0 ? a.id[ri.w] : 0.f;
+            const float idsv = a.id_mode == 2 && ri.w != kNoRow ? a.id[ri.w] : 0.f;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int ne = n + e;

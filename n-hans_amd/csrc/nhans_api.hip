@@ -479,7 +479,10 @@ float* run_stack_chunk(nhans_ctx* c, const float* logmag, const StackBufs& sb, i
     // frame b's 35 x 201 image = rows g0 + b - 17 ... of the log-magnitude spectrogram, zero rows outside its clip
     // (SN/apply.py:170-186,378: strided_crop, never materialised -- the first conv and the 1 -> 64 residual of
     // resblock1_1 read the spectrogram where it lies)
-    const WinRows win{sb.f_t + g0, sb.f_T + g0, (int)g0 - kCenter, kCenter};
+    // (rows are counted from the chunk's first frame -- the tensor pointer handed to the kernels is logmag + g0 * 201 --, so the
+    // kernels' 32-bit element indices stay below (frames_per_chunk + 35) * 201 however long the batch is)
+    const WinRows win{sb.f_t + g0, sb.f_T + g0, -kCenter, kCenter};
+    const float* const lm_chunk = logmag + (size_t)g0 * kBins;
     float *x = sb.X, *a1 = sb.A, *y = sb.Y;
     // pass 0 plans the WHOLE stack whatever `upto` is -- the layout of block b's output follows from block b + 1's
     // readers, and the debug entry point (upto = block + 1) must see the tensors the production call writes
@@ -490,7 +493,7 @@ float* run_stack_chunk(nhans_ctx* c, const float* logmag, const StackBufs& sb, i
         const float* cb2 = sb.cb_all + c->cond_off[2 * b + 1];
         if (b == 0) {
             DirectArgs d{};
-            d.src = logmag; d.win = win; d.w = c->A(p + ".c1.w"); d.H = g.hin; d.W = g.win; d.KH = g.kh; d.KW = g.kw;
+            d.src = lm_chunk; d.win = win; d.w = c->A(p + ".c1.w"); d.H = g.hin; d.W = g.win; d.KH = g.kh; d.KW = g.kw;
             d.sh = 1; d.sw = 1;
             int o; same_pad(g.hin, g.kh, 1, &o, &d.pt); same_pad(g.win, g.kw, 1, &o, &d.pl);
             d.Ho = g.hout; d.Wo = g.wout; d.M = n * g.hout * g.wout; d.out = a1;
@@ -535,7 +538,7 @@ float* run_stack_chunk(nhans_ctx* c, const float* logmag, const StackBufs& sb, i
         a.in_f32 = stored_f32(c, plan, b, 0); a.out_split = c->prec && !stored_f32(c, plan, b, 1);
         float* out;
         if (b == 0) {                       // 1 -> 64 transform on the window image itself
-            a.id_mode = 2; a.id = logmag; a.id_win = win; a.idH = g.hin; a.idW = g.win; a.idsh = 1; a.idsw = 1;
+            a.id_mode = 2; a.id = lm_chunk; a.id_win = win; a.idH = g.hin; a.idW = g.win; a.idsh = 1; a.idsw = 1;
             out = x;
         } else if (g.cin == g.cout) {       // identity shortcut, written in place over the block input
             a.id_mode = 1; a.id = x; a.id_ld = g.cout; a.id_split = c->prec && !stored_f32(c, plan, b - 1, 1);

@@ -85,8 +85,9 @@ __device__ __forceinline__ uint32_t fd_div(uint32_t n, const FastDiv& f) {
 struct WinRows {
     const int* t;
     const int* T;
-    int row0, pad;
+    int row0, pad;      // (row0 may be negative: nhans_api.hip counts rows from the launch's first frame, row0 = -pad)
 };
+constexpr int kNoRow = -2147483647 - 1;      // "this row is a zero row" where an element index is stored (conv_epilogue.h)
 __device__ __forceinline__ bool win_row_ok(const WinRows& w, int b, int h) {
     return (unsigned)(w.t[b] + h - w.pad) < (unsigned)w.T[b];
 }

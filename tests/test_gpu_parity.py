@@ -530,3 +530,35 @@ def test_debug_block_output_sees_the_production_layouts(_eng_d):
         got = torch.cat([_eng_d.block_output(lm, [0, 308], ea, eb, f, 1, b) for f in tf]).cpu().numpy()
         ref = g["block%d" % b]
         assert np.abs(got.reshape(-1)[::97] - ref).max() < 1e-4 * max(1.0, np.abs(ref).max()), b
+
+
+@pytest.mark.parametrize("wino", [1, 0])
+@pytest.mark.parametrize("prec", ["f16x3", "f32"])
+def test_windows_of_a_clip_that_began_before_the_chunk(_eng_d, prec, wino):
+    """The first layer and the 1 -> 64 residual of resblock1_1 read their 35-row windows out of the spectrogram itself
+    (WinRows, SN/apply.py:170-186,378), rows counted from the chunk's first frame: for a clip that straddles a chunk
+    boundary the first frames of the next chunk look BACK across it (negative row indices that are valid), the last frames of
+    a clip see zero rows ahead.  Three clips (40 / 3 / 57 frames) in chunks of 16 frame windows against the same clips in
+    one chunk and run alone, bit for bit, in every kernel family that has such a reader: the Winograd epilogue (f16x3),
+    the direct kernels' sweep (f16x3 with winograd = 0) and the f32 kernels."""
+    _eng_d.set_precision(prec)
+    _eng_d.set_option("winograd", wino)
+    g = torch.Generator().manual_seed(11)
+    nfr = [40, 3, 57]
+    lm = (torch.randn(sum(nfr), 201, generator=g) * 2.0 - 4.0).cuda()
+    ea = (torch.randn(3, 512, generator=g) * 0.1).cuda()
+    eb = (torch.randn(3, 512, generator=g) * 0.1).cuda()
+    foff = [0, 40, 43, 100]
+    try:
+        _eng_d.set_option("frames_per_chunk", 3776)
+        whole = _eng_d.mask_net(lm, foff, ea, eb)[0].cpu().numpy()
+        _eng_d.set_option("frames_per_chunk", 16)
+        chunked = _eng_d.mask_net(lm, foff, ea, eb)[0].cpu().numpy()
+        assert np.array_equal(whole, chunked)
+        for i in range(3):
+            solo = _eng_d.mask_net(lm[foff[i]:foff[i + 1]].contiguous(), [0, nfr[i]], ea[i:i + 1], eb[i:i + 1])[0].cpu().numpy()
+            assert np.array_equal(solo, whole[foff[i]:foff[i + 1]]), i
+    finally:
+        _eng_d.set_option("frames_per_chunk", 3776)
+        _eng_d.set_option("winograd", 1)
+    assert _eng_d.take_status() == 0
