@@ -109,8 +109,17 @@ def cpu_baseline(W, kind, mix, ca, cb, frames, threads):
     out = ref.enhance(mix, ca, cb, faithful=True, mb=frames, max_batches=1)
     dt = time.time() - t0
     n = out["frames_done"]
+    host_cpu = None
+    try:
+        with open("/proc/cpuinfo") as f:
+            host_cpu = next((l.split(":", 1)[1].strip() for l in f if l.startswith("model name")), None)
+    except OSError:
+        pass
     res = {"value": (n / dt) / 100.0, "unit": "audio-seconds/s", "cores": torch.get_num_threads(), "kind": "port",
+           "host_cpu": host_cpu, "host_logical_cpus": os.cpu_count(),
            "frames_per_s": n / dt,
+           # reference-faithful work per frame (40,483.6 GFLOP per 998-frame clip)
+           "gflops": (n / dt) * 40483.6 / 998.0,
            "sample": "first %d-frame minibatch of clip 0 of the workload, float32 torch-CPU restatement in "
                      "reference-faithful mode (both 200-frame contexts tiled per frame, embedding towers re-run "
                      "inside the minibatch, SN/apply.py:381-387,440-446), %.1f s" % (n, dt)}
