@@ -248,6 +248,15 @@ def test_library_exports_every_declared_symbol(lib_built):
     out = ctypes.c_void_p()
     assert h.nhans_create(0, bad, 64, 0, ctypes.byref(out)) == -1            # NHANS_EINVAL: bad magic
     assert b"magic" in h.nhans_last_error()
+    # nhans_create_ex (ABI 5): the exponents are checked before anything touches a device
+    ok = (ctypes.c_int * hip.NUM_ACTIVATIONS)(*([0] * hip.NUM_ACTIVATIONS))
+    assert h.nhans_create_ex(0, bad, 64, 0, ok, hip.NUM_ACTIVATIONS - 1, ctypes.byref(out)) == -1
+    assert b"NHANS_NUM_ACTIVATIONS" in h.nhans_last_error()
+    far = (ctypes.c_int * hip.NUM_ACTIVATIONS)(*([0] * (hip.NUM_ACTIVATIONS - 1) + [61]))
+    assert h.nhans_create_ex(0, bad, 64, 0, far, hip.NUM_ACTIVATIONS, ctypes.byref(out)) == -1
+    assert b"outside [-60, 60]" in h.nhans_last_error()
+    assert h.nhans_create_ex(0, bad, 64, 0, ok, hip.NUM_ACTIVATIONS, ctypes.byref(out)) == -1 and b"magic" in h.nhans_last_error()
+    assert h.nhans_create_ex(0, bad, 64, 0, None, 0, ctypes.byref(out)) == -1 and b"magic" in h.nhans_last_error()
 
 
 def test_launch_failure_returns_negative_code(lib_built):
