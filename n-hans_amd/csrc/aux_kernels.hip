@@ -195,11 +195,7 @@ __global__ void __launch_bounds__(256) direct_conv64_4x4(const DirectArgs a, int
                         // a split store -- the reader's transform re-splits what it reads)
                         if (a.sat && split_clamp(acc, a.sat_limit)) atomicOr(a.sat, kSatActivation);
                         typedef float fx4 __attribute__((ext_vector_type(4)));
-#ifdef D4_PLAIN_STORE
-                        *reinterpret_cast<fx4*>(op) = fx4{acc.x, acc.y, acc.z, acc.w};
-#else
                         __builtin_nontemporal_store(fx4{acc.x, acc.y, acc.z, acc.w}, reinterpret_cast<fx4*>(op));
-#endif
                     }
                     op += out_step;
                 }
@@ -277,10 +273,7 @@ void launch_direct_conv64(const DirectArgs& a, hipStream_t s) {
     if (a.KH == 4 && a.KW == 4 && a.sh == 1 && a.sw == 1 && a.Ho <= D4_TR && a.M % (a.Ho * a.Wo) == 0) {
         const int tiles_r = (a.Ho + D4_TR - 1) / D4_TR, tiles_c = (a.Wo + 15) / 16;
         const int ntiles = (a.M / (a.Ho * a.Wo)) * tiles_r * tiles_c;
-#ifndef D4_GRID
-#define D4_GRID 8
-#endif
-        const int grid4 = ntiles < 256 * D4_GRID ? ntiles : 256 * D4_GRID;
+        const int grid4 = ntiles < 256 * 8 ? ntiles : 256 * 8;
         if (a.out_split) NHANS_LAUNCH("direct_conv64_4x4", direct_conv64_4x4<1>, dim3(grid4), dim3(256), 0, s, a, tiles_r, tiles_c, ntiles);
         else NHANS_LAUNCH("direct_conv64_4x4", direct_conv64_4x4<0>, dim3(grid4), dim3(256), 0, s, a, tiles_r, tiles_c, ntiles);
         return;
