@@ -3,7 +3,8 @@ library calibrated for it -- what stands between `nhans_denoiser one.wav` and it
 is one process per file).  An entry is keyed by
     sha256( what the weights are | fold.BLOB_VERSION | C-ABI version | model kind )
 where "what the weights are" is, for a TensorFlow bundle, the bytes of its .index file (every tensor's shape, offset and
-masked crc32c) + the size of its data file -- content-addressed without hashing 126 MB on every start -- and for the
+masked crc32c) + the size and modification time of its data file -- content-addressed without hashing 126 MB on every
+start -- and for the
 seeded synthetic weights the seed and the text of the recipe (weights.py).  Files: <dir>/<key>.blob (the exact bytes
 fold_weights returns) and <dir>/<key>.json ({"exponents": [...], "blob_sha256": ...}), written through a temporary name
 and renamed, so a reader never sees half a file; a blob whose size or BLOB_VERSION header does not match is ignored and
@@ -34,8 +35,10 @@ def key_for_checkpoint(prefix, kind):
     """prefix = path of the bundle without .index / .data-00000-of-00001"""
     with open(prefix + ".index", "rb") as f:
         index = f.read()
-    size = os.path.getsize(prefix + ".data-00000-of-00001")
-    return _key([b"tf-bundle", index, size, fold.BLOB_VERSION, hip.ABI_VERSION, kind])
+    st = os.stat(prefix + ".data-00000-of-00001")
+    # (size AND modification time of the data file: a data file that was replaced under an unchanged .index -- which the
+    # per-tensor CRCs would catch at load time -- must not be served from the cache unread)
+    return _key([b"tf-bundle", index, st.st_size, st.st_mtime_ns, fold.BLOB_VERSION, hip.ABI_VERSION, kind])
 
 
 def key_for_synthetic(kind, seed):
