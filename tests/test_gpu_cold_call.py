@@ -25,7 +25,7 @@ def _write_inputs(d):
     wavfile.write(os.path.join(d, "neg.wav"), 16000, synth.noise_context(71))
 
 
-def _cli_worker(d, tag, extra, q):
+def _cli_worker(d, tag, extra, q, prog="denoiser"):
     try:
         import sys
         root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -39,8 +39,12 @@ def _cli_worker(d, tag, extra, q):
         err, old = io.StringIO(), sys.stderr
         sys.stderr = err
         try:
-            apply.main(["--input", os.path.join(d, "in.wav"), "--neg", os.path.join(d, "neg.wav"), "--pos", os.path.join(d, "Silent.wav"),
-                        "--output", os.path.join(d, tag + ".wav"), "--weights", "synthetic", "--timing"] + list(extra))
+            if prog == "separator":
+                apply.main_separator(["--input", os.path.join(d, "in.wav"), "--neg", os.path.join(d, "neg.wav"), "--pos", os.path.join(d, "pos.wav"),
+                                      "--output", os.path.join(d, tag + ".wav"), "--weights", "synthetic", "--timing"] + list(extra))
+            else:
+                apply.main(["--input", os.path.join(d, "in.wav"), "--neg", os.path.join(d, "neg.wav"), "--pos", os.path.join(d, "Silent.wav"),
+                            "--output", os.path.join(d, tag + ".wav"), "--weights", "synthetic", "--timing"] + list(extra))
         finally:
             sys.stderr = old
         timing = None
@@ -53,10 +57,10 @@ def _cli_worker(d, tag, extra, q):
         q.put((tag, None, None, None, traceback.format_exc() + repr(e)))
 
 
-def _run_cli(d, tag, extra=()):
+def _run_cli(d, tag, extra=(), prog="denoiser"):
     ctx = mp.get_context("forkserver")
     q = ctx.Queue()
-    p = ctx.Process(target=_cli_worker, args=(d, tag, extra, q))
+    p = ctx.Process(target=_cli_worker, args=(d, tag, extra, q, prog))
     p.start()
     try:
         res = q.get(timeout=600)
@@ -141,3 +145,26 @@ def test_fresh_process_cli_is_torch_free_and_uses_the_cache(lib_built, tmp_path)
     assert third[3]["cache"] == "miss"
     assert open(os.path.join(d, "third.wav"), "rb").read() == open(os.path.join(d, "first.wav"), "rb").read()
     assert os.path.getsize(os.path.join(cache, blobs[0])) > (100 << 20)
+
+
+def test_fresh_process_separator_cli_equals_the_full_engine(lib_built, tmp_path):
+    """`nhans_separator` (setup.py:48, SS/apply.py:288-397) through the torch-free engine and its own cache entry: the same
+    bytes as engine.Engine with the separator's (interferer, target) conditioning order."""
+    from scipy.io import wavfile
+    import nhans_amd  # noqa: F401
+    from nhans_amd import apply, engine, synth, weights
+    d = str(tmp_path)
+    _write_inputs(d)
+    wavfile.write(os.path.join(d, "pos.wav"), 16000, synth.speaker_context(72, low=False))
+    first = _run_cli(d, "sep1", prog="separator")
+    second = _run_cli(d, "sep2", prog="separator")
+    assert first[2] is False and first[3]["engine"] == "LiteEngine" and first[3]["cache"] == "miss"
+    assert second[3]["cache"] == "hit"
+    assert open(os.path.join(d, "sep1.wav"), "rb").read() == open(os.path.join(d, "sep2.wav"), "rb").read()
+    eng = engine.Engine("separator", weights.synthetic_weights("separator", 7), precision="f16x3")
+    mix = apply.trim_to_frames(apply.normalise(apply.read_wav(os.path.join(d, "in.wav"))))
+    neg = apply.normalise(apply.extend_context(apply.read_wav(os.path.join(d, "neg.wav"))))     # interferer: context a
+    pos = apply.normalise(apply.extend_context(apply.read_wav(os.path.join(d, "pos.wav"))))     # target: context b
+    ref = eng.enhance([mix], [neg], [pos], want_mixed=False)["denoised_wav"][0]
+    eng.close()
+    assert np.array_equal(wavfile.read(os.path.join(d, "sep1.wav"))[1], ref)
