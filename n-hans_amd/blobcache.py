@@ -79,7 +79,7 @@ def store(key, blob, exponents=None):
         os.replace(tmp + ".blob", base + ".blob")
         meta = {"nbytes": int(arr.size), "blob_version": fold.BLOB_VERSION, "abi_version": hip.ABI_VERSION,
                 "exponents": None if exponents is None else [int(e) for e in exponents],
-                "blob_sha256": hashlib.sha256(arr.tobytes() if arr.size < (64 << 20) else arr[:64 << 20].tobytes()).hexdigest()}
+                "blob_sha256": hashlib.sha256(memoryview(np.ascontiguousarray(arr))).hexdigest()}      # (the whole blob; on a miss only)
         with open(tmp + ".json", "w") as f:
             json.dump(meta, f)
         os.replace(tmp + ".json", base + ".json")
