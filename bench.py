@@ -428,7 +428,7 @@ def main(argv=None):
     if rank == 0:
         ms_step = 1e3 * dt / a.steps
         cap_tf = ceiling["sustained_tflops"] if ceiling else None
-        convs = {k: v for k, v in prof.items() if k.startswith("conv_igemm") or k.startswith("conv_wino")}
+        convs = {k: v for k, v in prof.items() if k.startswith(("conv_igemm", "conv_wino", "conv_1x1"))}
         conv_ms = sum(v["ms"] for v in convs.values())
         conv_fl = sum(v["flops"] for v in convs.values())
         conv_calls = sum(v["calls"] for v in convs.values())

@@ -138,6 +138,9 @@ void nhans_destroy(nhans_ctx* ctx);
  *           computed on a wrong layout; 3: a TEST value -- only the output of resblock1_2 is f32: its conv2 then has a
  *           split residual and an f32 output, the one layout pair the Winograd epilogue does not implement, and the launch
  *           is refused the same way.  After a refused or failed launch nothing further of that pass is launched.),
+ *          "stream_1x1" (1, default: the stand-alone 1x1 strided `_transform` conv of resblock2_1 -- an HBM stream, 1.75 GB in and
+ *           3.5 GB out per pass -- runs on its own streaming kernel, conv_1x1_stream.hip; 0: on the generic implicit-GEMM kernel.
+ *           Identical bits),
  *          "split_k" (1, default: the launches too small to fill the chip -- the head's dense layer, the embedding tower
  *           at a few clips -- run one workgroup per (tile, K group) through a scratch buffer; 0: every workgroup walks
  *           its K groups itself.  The groups and the order of the additions depend on the layer only: identical bits),

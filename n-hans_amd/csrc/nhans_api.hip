@@ -122,6 +122,7 @@ struct nhans_ctx {
     size_t kscratch_bytes = 0;
     static constexpr size_t kscratch_cap = (size_t)384 << 20;
     bool kscratch_failed = false;
+    int stream_1x1 = 1;         // option stream_1x1: the stand-alone `_transform` conv on conv_1x1_stream.hip (0: the generic conv kernel; same bits)
     int split_k = 1;            // option split_k: 0 = never split (the grouped walk inside one workgroup: same bits)
     int* kcounter = nullptr;
     int kcounter_n = 1024;
@@ -564,7 +565,16 @@ float* run_stack_chunk(nhans_ctx* c, const float* logmag, const StackBufs& sb, i
                 t.ws = c->WS(p + ".c2");            // (conv2 and the transform share one column scale: fold.py emit())
                 t.relu = 0; t.out_split = 0;
                 t.in_scale = c->up(SA(b - 1, 1));   // (f32 output: no exponent)
-                if (go && !dead()) run_conv(c, t, s);
+                if (go && !dead()) {
+                    if (c->stream_1x1 && conv_1x1_stream_eligible(t)) {       // 1.75 GB in, 3.5 GB out, 16 KFLOP per output pixel: a stream
+                        Prof pr(c, s, "conv_1x1_stream");
+                        launch_conv_1x1_stream(t, s);
+                        const double fl = 2.0 * (double)t.M * g.cin * g.cout;
+                        pr.done(fl, (double)t.M * (g.cin + g.cout) * 4.0, nullptr, 3.0 * fl);
+                    } else {
+                        run_conv(c, t, s);
+                    }
+                }
                 a = w;
             } else {                        // (x and a1 share one exponent)
                 a.nseg = 2;
@@ -1029,6 +1039,7 @@ int nhans_set_option(nhans_ctx* c, const char* key, int64_t value) {
     else if (k == "winograd") c->wino = value != 0;
     else if (k == "winograd_f32_tensors") c->wino_f32 = (value == 2 || value == 3) ? (int)value : value != 0;
     else if (k == "split_k") c->split_k = value != 0;
+    else if (k == "stream_1x1") c->stream_1x1 = value != 0;
     else if (k == "precision") {
         if (value != 0 && value != 1) return fail(NHANS_EINVAL, "precision must be 0 (f32) or 1 (f16x3)");
         if (value == 1 && !c->A("head.dense.wpk_h"))

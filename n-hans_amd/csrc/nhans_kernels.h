@@ -193,6 +193,20 @@ bool conv_igemm_halo_pw_eligible(const ConvArgs& a);            // the same pipe
 void launch_conv_igemm_halo_pw(const ConvArgs& a, hipStream_t s);
 
 // ---------------------------------------------------------------------------------------------
+// The stand-alone 1x1 strided `_transform` conv of resblock2_1 as a stream (conv_1x1_stream.hip): 64 split-NHWC channels in,
+// 128 f32 channels out, out = (x W) * ws * in_scale -- the arithmetic of conv_igemm_dma.hip for that launch, bit for bit
+struct Stream1x1Args {
+    const float* src;      // split NHWC [B, H, W, 64]
+    const float* wpk;      // fold.py pack_igemm_h3 of the [64, 128] matrix
+    const float* ws;       // [128] per-channel power of two that undoes the weight pre-scaling
+    float in_scale;
+    float* out;            // f32 [M, 128]
+    int H, W, sh, sw, M;
+    FastDiv fdHoWo, fdWo;
+};
+bool conv_1x1_stream_eligible(const ConvArgs& t);
+void launch_conv_1x1_stream(const ConvArgs& t, hipStream_t s);
+
 // Small kernels (aux_kernels.hip)
 struct DirectArgs {     // convolution of a 1-channel image into 64 channels, same epilogue terms
     const float* src;   // [B, H, W] -- or, win.t != nullptr, the [rows, W] tensor the images are sliding windows of

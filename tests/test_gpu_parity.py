@@ -562,3 +562,37 @@ def test_windows_of_a_clip_that_began_before_the_chunk(_eng_d, prec, wino):
         _eng_d.set_option("frames_per_chunk", 3776)
         _eng_d.set_option("winograd", 1)
     assert _eng_d.take_status() == 0
+
+
+def test_transform_conv_stream_kernel_is_bit_identical_to_the_generic_kernel(_eng_d):
+    """conv_1x1_stream.hip runs resblock2_1's stand-alone 1x1 strided `_transform` conv (SN/main.py:176-181) as a stream -- a wave
+    per 32 output pixels, weights in registers, results straight from the accumulators -- with the generic kernel's
+    arithmetic: same products in the same order.  Option stream_1x1 = 0 puts the launch back on conv_igemm_dma.hip: the
+    block outputs from resblock2_1 on and the logits must agree bit for bit, on a frame count that leaves a partial
+    32-pixel group (7 frames x 1,818 pixels) and on two chunks; and the profile shows which kernel ran."""
+    _eng_d.set_precision("f16x3")
+    g = load_case("case_exp2")
+    lm = torch.from_numpy(g["logmag"]).cuda()
+    ea = torch.from_numpy(g["emb_a"][None]).cuda()
+    eb = torch.from_numpy(g["emb_b"][None]).cuda()
+    out = {}
+    try:
+        for v in (0, 1):
+            _eng_d.set_option("stream_1x1", v)
+            _eng_d.set_option("profile", 1)
+            _eng_d.profile_reset()
+            blk = _eng_d.block_output(lm, [0, 308], ea, eb, 100, 7, 2).cpu().numpy()
+            _eng_d.set_option("frames_per_chunk", 200)
+            lg = _eng_d.mask_net(lm, [0, 308], ea, eb)[0].cpu().numpy()
+            _eng_d.set_option("frames_per_chunk", 3776)
+            names = set(_eng_d.profile())
+            assert ("conv_1x1_stream" in names) == bool(v), names
+            out[v] = (blk, lg)
+    finally:
+        _eng_d.set_option("profile", 0)
+        _eng_d.set_option("stream_1x1", 1)
+        _eng_d.set_option("frames_per_chunk", 3776)
+    assert np.array_equal(out[0][0], out[1][0])
+    assert np.array_equal(out[0][1], out[1][1])
+    assert np.abs(out[1][1] - g["logits"]).max() < LOGIT_TOL
+    assert _eng_d.take_status() == 0

@@ -9,6 +9,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
+#include <algorithm>
 typedef float fx4 __attribute__((ext_vector_type(4)));
 typedef float fx2 __attribute__((ext_vector_type(2)));
 
@@ -72,6 +73,31 @@ __global__ void __launch_bounds__(256) k_rw(const char* src, char* dst, size_t b
     }
 }
 
+// _transform's REAL access pattern (resblock2_1: 1x1 conv, stride 2, 64 -> 128 channels): input image 35 x 201 pixels of 256 B,
+// output 18 x 101 pixels of 512 B; output pixel (ho, wo) reads input pixel (2 ho, 2 wo) -- every other 256-byte pixel of every
+// other image row -- and writes 512 contiguous bytes.  16 lanes per input pixel (16 B each).
+template <int NT>
+__global__ void __launch_bounds__(256) k_rw_strided(const char* src, char* dst, int frames) {
+    const int per = 18 * 101;
+    const long long total = (long long)frames * per * 16;            // 16-byte pieces to read
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const long long px = i >> 4;
+        const int piece = (int)(i & 15);
+        const int f = (int)(px / per), r = (int)(px - (long long)f * per);
+        const int ho = r / 101, wo = r - ho * 101;
+        const size_t in = (((size_t)f * 35 + 2 * ho) * 201 + 2 * wo) * 256 + piece * 16;
+        const fx4 x = __builtin_nontemporal_load(reinterpret_cast<const fx4*>(src + in));
+        const size_t out = (size_t)px * 512 + piece * 16;
+        if constexpr (NT) {
+            __builtin_nontemporal_store(x, reinterpret_cast<fx4*>(dst + out));
+            __builtin_nontemporal_store(x, reinterpret_cast<fx4*>(dst + out + 256));
+        } else {
+            *reinterpret_cast<fx4*>(dst + out) = x;
+            *reinterpret_cast<fx4*>(dst + out + 256) = x;
+        }
+    }
+}
+
 static hipEvent_t e0, e1;
 template <class F>
 static void run(const char* name, double bytes, F f) {
@@ -123,6 +149,17 @@ int main(int argc, char** argv) {
         const size_t in = bytes / 2 / 2;                      // reads `in`, writes 2 * in
         run("1 : 2 read : write, nt stores (bytes = read + written)", 3.0 * in, [&] { hipLaunchKernelGGL((k_rw<1>), dim3(2048), dim3(256), 0, 0, src, dst, in); });
         run("1 : 2 read : write, default stores (bytes = read + written)", 3.0 * in, [&] { hipLaunchKernelGGL((k_rw<0>), dim3(2048), dim3(256), 0, 0, src, dst, in); });
+    }
+    {
+        // as many frames as the buffers hold: input 35*201*256 B per frame must fit src (bytes / 2), output 18*101*512 B dst
+        const int frames = (int)std::min((bytes / 2) / (35.0 * 201 * 256), bytes / (18.0 * 101 * 512));
+        const double moved = (double)frames * 18 * 101 * (256 + 512);
+        run("_transform's pattern: stride-2 pixel reads (256 of every 512 B, every other row), 512 B written each, nt (bytes = read + written)",
+            moved, [&] { hipLaunchKernelGGL((k_rw_strided<1>), dim3(2048), dim3(256), 0, 0, src, dst, frames); });
+        run("_transform's pattern, default stores (bytes = read + written)",
+            moved, [&] { hipLaunchKernelGGL((k_rw_strided<0>), dim3(2048), dim3(256), 0, 0, src, dst, frames); });
+        run("_transform's pattern, nt, 256 x 16 workgroups (bytes = read + written)",
+            moved, [&] { hipLaunchKernelGGL((k_rw_strided<1>), dim3(4096), dim3(256), 0, 0, src, dst, frames); });
     }
     return 0;
 }
